@@ -1,0 +1,236 @@
+/*
+ * rt_amd.h — C ABI of the MI355X wavefront path-tracing backend.
+ *
+ * The reference renderer (sedcftyv/RayTracing) has no FFI or plugin API; its two
+ * seams are C++ virtual interfaces:
+ *   - Integrator::Render(const Scene&, int w, int h)      include/core/integrator.h:17-21
+ *   - Primitive::Intersect / IntersectP (Aggregate)       include/core/primitive.h:10-19,39-44
+ * Every entry point below replaces one of those seams (or a helper that the
+ * reference calls behind them) and cites it.  The host-side C++ classes under
+ * raytracing_amd/host/ keep the reference's class names and constructor
+ * signatures and call into this ABI from PathIntegrator::Render.
+ *
+ * Conventions: plain pointers and sizes, caller-owned host memory unless a
+ * function says "device"; the library copies what it is given; 0 = success,
+ * negative = error (rt_last_error() returns the text); no exceptions cross the
+ * boundary; one host thread drives a context at a time; calls are synchronous
+ * unless the name ends in _async.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- data -- */
+
+/* One flattened BVH node; byte-for-byte the reference's LinearBVHNode
+ * (include/core/bvh.cpp:43-47): depth-first order, first child = index+1. */
+typedef struct rt_bvh_node {
+    float    bmin[3];
+    float    bmax[3];
+    int32_t  offset;   /* leaf: first slot in prim_order; interior: index of second child */
+    uint16_t nprim;    /* 0 = interior */
+    uint8_t  axis;     /* interior: split axis 0/1/2 */
+    uint8_t  pad;
+} rt_bvh_node;
+
+enum { RT_PRIM_TRIANGLE = 0, RT_PRIM_SPHERE = 1 };
+
+/* A sphere as the reference stores it (include/core/sphere.h, sphere.cpp:29-73):
+ * radius plus both 4x4 row-major matrices of its Transform. */
+typedef struct rt_sphere {
+    float radius;
+    float o2w[16];
+    float w2o[16];
+} rt_sphere;
+
+enum {
+    RT_TEX_CONST = 0,  /* ConstantTexture<Spectrum> or <Float> (value[0] used for Float) */
+    RT_TEX_IMAGE = 1   /* ImageTexture<RGBSpectrum,Spectrum>: level-0 float RGB, Repeat, bilinear */
+};
+
+/* include/core/texture.h:18-25 (constant), include/core/imagemap.h:36-51 +
+ * include/core/mipmap.h:190-200 (image, level 0 after the pow-2 resample). */
+typedef struct rt_texture {
+    int32_t      kind;
+    int32_t      width, height;   /* image only */
+    float        value[3];        /* constant only */
+    const float *texels;          /* image only: height*width*3 floats, row-major, row 0 first */
+    float        su, sv, du, dv;  /* UVMapping2D (include/core/texture.cpp:5-13); image only */
+} rt_texture;
+
+enum {
+    RT_MAT_MATTE      = 0,  /* tex[0]=Kd                                   material.cpp:5-10  */
+    RT_MAT_MIRROR     = 1,  /* tex[0]=Kr                                   material.cpp:12-20 */
+    RT_MAT_GLASS      = 2,  /* tex[0]=Kr tex[1]=Kt tex[2]=index            material.cpp:22-30 */
+    RT_MAT_METAL      = 3,  /* tex[0]=eta tex[1]=k tex[2]=urough tex[3]=vrough, flag remap
+                               (urough/vrough already resolved against `roughness`) material.cpp:51-67 */
+    RT_MAT_PLASTIC    = 4,  /* tex[0]=Kd tex[1]=Ks tex[2]=roughness, flag remap material.cpp:32-49 */
+    RT_MAT_METALROUGH = 5   /* tex[0]=base_color tex[1]=metalroughness or -1    material.cpp:69-82 */
+};
+
+typedef struct rt_material {
+    int32_t kind;
+    int32_t tex[4];          /* indices into rt_scene_desc.textures, -1 = absent */
+    int32_t remap_roughness; /* METAL / PLASTIC */
+    int32_t pad;
+} rt_material;
+
+/* DiffuseAreaLight on one triangle (include/core/light.cpp:28-54, light.h:68-89). */
+typedef struct rt_light {
+    int32_t prim;        /* index into the ORIGINAL primitive list */
+    float   Le[3];
+    int32_t two_sided;
+    float   area;        /* Shape::Area() as the reference caches it */
+} rt_light;
+
+/* The whole scene, flattened.  Primitive arrays are in the ORIGINAL order the
+ * scene script pushed them (RayTracing.cpp: prims.push_back); prim_order maps a
+ * BVH leaf slot to that original index (the reference's orderedPrims,
+ * bvh.cpp:97-103).  bvh_nodes may be NULL: rt_scene_create then builds the tree
+ * with rt_bvh_build. */
+typedef struct rt_scene_desc {
+    int32_t            n_prims;
+    const uint8_t     *prim_kind;      /* RT_PRIM_*                                  */
+    const int32_t     *prim_geom;      /* index into tri_* or spheres                */
+    const int32_t     *prim_material;  /* index into materials                       */
+    const int32_t     *prim_light;     /* index into lights, -1 = not an emitter     */
+
+    int32_t            n_tris;
+    const float       *tri_p;          /* n_tris*9: world-space p0,p1,p2 (triangle.cpp:19-20) */
+    const float       *tri_uv;         /* n_tris*6: uv0,uv1,uv2 ((0,0),(1,0),(1,1) if the mesh has none, triangle.h:46-57) */
+    const float       *tri_n;          /* n_tris*9 world-space vertex normals, or NULL */
+    const uint8_t     *tri_has_n;      /* n_tris, or NULL */
+
+    int32_t            n_spheres;
+    const rt_sphere   *spheres;
+
+    int32_t            n_materials;
+    const rt_material *materials;
+    int32_t            n_textures;
+    const rt_texture  *textures;
+    int32_t            n_lights;
+    const rt_light    *lights;
+
+    int32_t            n_nodes;
+    const rt_bvh_node *bvh_nodes;      /* optional */
+    const int32_t     *prim_order;     /* n_prims, required iff bvh_nodes != NULL */
+} rt_scene_desc;
+
+/* PerspectiveCamera state that GenerateRay reads (include/core/camera.cpp:52-58,
+ * camera.h:24-45): both row-major 4x4 matrices. */
+typedef struct rt_camera {
+    float   raster_to_camera[16];
+    float   camera_to_world[16];
+    int32_t width, height;
+} rt_camera;
+
+typedef struct rt_render_opts {
+    int32_t  strata_x, strata_y;   /* StratifiedSampler(x, y, jitter=true, 1): spp = x*y (stratified.h:11-15) */
+    int32_t  sample_begin, sample_end; /* this call renders samples [begin,end) of every pixel */
+    int32_t  max_depth;            /* PathIntegrator maxDepth (RayTracing.cpp:431 passes 50) */
+    uint32_t seed_lo, seed_hi;     /* Philox key */
+    int32_t  pool_paths;           /* path slots kept in flight; 0 = library default */
+    int32_t  flags;                /* RT_RENDER_* */
+} rt_render_opts;
+
+enum {
+    RT_RENDER_ACCUMULATE = 1  /* add onto the existing contents of the sum buffer instead of clearing it */
+};
+
+typedef struct rt_render_stats {
+    uint64_t samples;          /* camera paths started */
+    uint64_t rays_closest;     /* closest-hit traversals */
+    uint64_t rays_shadow;      /* any-hit traversals */
+    uint64_t iterations;       /* wavefront iterations */
+    double   seconds_total;    /* device time, HIP events on the library's stream */
+    double   seconds_trace;    /* closest-hit kernel  */
+    double   seconds_shade;    /* shading kernels     */
+    double   seconds_shadow;   /* any-hit kernel      */
+} rt_render_stats;
+
+typedef struct rt_trace_stats {
+    uint64_t nodes_visited;    /* slab tests performed (reference traversal order) */
+    uint64_t prims_tested;     /* primitive tests performed */
+    double   seconds;          /* average kernel time over `repeats`, HIP events */
+} rt_trace_stats;
+
+typedef struct rt_ctx   rt_ctx;
+typedef struct rt_scene rt_scene;
+
+/* ------------------------------------------------------------ functions -- */
+
+/* Library version string. */
+const char *rt_version(void);
+
+/* Create a context bound to HIP device `device` (one process per GPU).
+ * Fails (negative) when no HIP device is present: there is no CPU fallback. */
+int rt_init(int device, rt_ctx **out);
+void rt_shutdown(rt_ctx *ctx);
+const char *rt_last_error(rt_ctx *ctx);   /* ctx may be NULL for rt_init failures */
+
+/* Host-side BVH builder with the reference's decisions (BVHAccel::BVHAccel /
+ * recursiveBuild / flattenBVHTree, include/core/bvh.cpp:63-245; SplitMethod::Middle,
+ * maxPrimsInNode = 1).  prim_bounds = n*6 floats (min xyz, max xyz) in original
+ * order.  nodes_out must hold 2*n-1 nodes, order_out n ints.  Needs no GPU. */
+int rt_bvh_build(int32_t n_prims, const float *prim_bounds,
+                 rt_bvh_node *nodes_out, int32_t *n_nodes_out, int32_t *order_out);
+
+/* World bounds of every primitive of a desc, n_prims*6 floats
+ * (Triangle::WorldBound triangle.cpp:45-50, Shape::WorldBound shape.cpp:16 for spheres). */
+int rt_prim_bounds(const rt_scene_desc *desc, float *bounds_out);
+
+/* Flatten + upload a scene (replaces the pointer graph behind Scene/BVHAccel,
+ * include/core/scene.h:9-24, bvh.h:15-37). */
+int rt_scene_create(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out);
+void rt_scene_destroy(rt_scene *scene);
+/* Copy the tree the scene uses back to the caller (for parity checks). */
+int rt_scene_get_bvh(rt_scene *scene, rt_bvh_node *nodes_out, int32_t *n_nodes_out, int32_t *order_out);
+
+/* Closest hit for a batch of rays — Scene::Intersect -> BVHAccel::Intersect
+ * (include/core/scene.cpp:15-18, bvh.cpp:247-282).  o, d: n*3 floats; tmax: n floats.
+ * out_prim: original primitive index or -1; out_t: hit distance (tmax on miss);
+ * out_b: n*2 barycentrics b1,b2 for triangles / (u,v) for spheres (may be NULL).
+ * Host pointers. */
+int rt_trace_closest(rt_scene *scene, size_t n, const float *o, const float *d, const float *tmax,
+                     int32_t *out_prim, float *out_t, float *out_b);
+
+/* Any hit — Scene::IntersectP -> BVHAccel::IntersectP (scene.cpp:20-23, bvh.cpp:284-320). */
+int rt_trace_any(rt_scene *scene, size_t n, const float *o, const float *d, const float *tmax,
+                 uint8_t *out_hit);
+
+/* Device-resident variants for measurement: pointers are HIP device pointers on
+ * the context's device, rays laid out SoA (ox[n] oy[n] oz[n] dx[n] dy[n] dz[n] tmax[n]
+ * contiguous in `rays`), results SoA (prim[n] as int32, then t[n], b1[n], b2[n]
+ * as float, contiguous in `hits`).  The kernel is launched `repeats` times on
+ * the library stream and timed with HIP events; stats may be NULL. */
+int rt_trace_closest_device(rt_scene *scene, size_t n, const void *rays, void *hits,
+                            int repeats, int count_work, rt_trace_stats *stats);
+
+/* Render samples [sample_begin, sample_end) of every pixel and return the
+ * per-pixel SUM of radiance (not the mean) — the loop of
+ * SamplerIntegrator::Render / render_pixel (include/core/integrator.cpp:317-412)
+ * around PathIntegrator::Li_re (integrator.cpp:236-281).
+ * out_sum_rgb: width*height*3 floats, row 0 = raster y 0, host memory. */
+int rt_render(rt_scene *scene, const rt_camera *cam, const rt_render_opts *opts,
+              float *out_sum_rgb, rt_render_stats *stats);
+
+/* Same, but the sum stays in a device buffer owned by the scene
+ * (width*height*3 floats); *out_device_sum receives its device pointer.  Used by
+ * the multi-GPU driver, which reduces the buffers with RCCL. */
+int rt_render_device(rt_scene *scene, const rt_camera *cam, const rt_render_opts *opts,
+                     void **out_device_sum, rt_render_stats *stats);
+
+/* mean -> NaN->0 -> sqrt -> 256*clamp(.,0,0.999) -> u8 — write_color
+ * (include/core/integrator.cpp:289-308).  Host, needs no GPU. */
+int rt_tonemap_u8(const float *sum_rgb, int32_t width, int32_t height, int32_t spp, uint8_t *out_rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

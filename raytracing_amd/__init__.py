@@ -1,0 +1,222 @@
+"""raytracing_amd — Python harness around the MI355X wavefront path-tracing backend.
+
+The product is the pair of in-tree shared libraries:
+  lib/librt_amd.so   HIP kernels + the C ABI of include/rt_amd.h
+  lib/librt_host.so  C++ scene surface with the reference's class names + the reference's scenes
+This package only binds them (ctypes) for tests and benchmarks.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+from .capi import Camera, RenderOpts, RenderStats, SceneDesc, TraceStats, BVH_NODE_DTYPE
+
+__all__ = ["HostScene", "Context", "DeviceScene", "bvh_build", "tonemap_u8", "default_assets_dir"]
+
+_rt = None
+_host = None
+
+
+def rt():
+    global _rt
+    if _rt is None:
+        _rt = capi.load_rt_amd()
+    return _rt
+
+
+def host():
+    global _host
+    if _host is None:
+        _host = capi.load_rt_host()
+    return _host
+
+
+def default_assets_dir():
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "assets")
+
+
+def register_image_file(path):
+    """Decode an image with PIL and hand the 8-bit RGB pixels to the host library under its file name."""
+    from PIL import Image
+    im = np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8))
+    host().rth_register_image(os.path.basename(path).encode(), im.shape[1], im.shape[0], capi.u8ptr(im))
+
+
+class HostScene:
+    """A scene built by the C++ host surface (raytracing_amd/host/scenes.cpp) and flattened to an rt_scene_desc."""
+
+    def __init__(self, name, param=0, assets_dir=None):
+        assets_dir = assets_dir or default_assets_dir()
+        if name == "spheres2":
+            register_image_file(os.path.join(assets_dir, "earthmap.jpg"))
+        if name == "helmet":
+            for f in ("Default_albedo.jpg", "Default_metalRoughness.jpg"):
+                register_image_file(os.path.join(assets_dir, "DamagedHelmet", "glTF", f))
+        self.name = name
+        self._h = host().rth_scene_build(name.encode(), assets_dir.encode(), int(param))
+        if not self._h:
+            raise RuntimeError("rth_scene_build(%s): %s" % (name, host().rth_last_error().decode()))
+        self.desc_ptr = host().rth_scene_desc(self._h)
+        self.desc = self.desc_ptr.contents
+
+    def camera(self, width, height):
+        cam = Camera()
+        if host().rth_scene_camera(self._h, width, height, C.byref(cam)) != 0:
+            raise RuntimeError("rth_scene_camera failed")
+        return cam
+
+    def nodes(self):
+        d = self.desc
+        buf = C.string_at(d.bvh_nodes, d.n_nodes * 32)
+        return np.frombuffer(buf, dtype=BVH_NODE_DTYPE).copy()
+
+    def prim_order(self):
+        d = self.desc
+        return np.ctypeslib.as_array(d.prim_order, shape=(d.n_prims,)).copy()
+
+    def tri_p(self):
+        d = self.desc
+        return np.ctypeslib.as_array(d.tri_p, shape=(d.n_tris, 3, 3)).copy()
+
+    def render_like_main(self, width, height, sx, sy, max_depth=50, png_path=None):
+        out = np.zeros((height, width, 3), np.float32)
+        st = RenderStats()
+        rc = host().rth_render_like_main(self._h, width, height, sx, sy, max_depth, png_path.encode() if png_path else None,
+                                         capi.fptr(out), C.byref(st))
+        if rc != 0:
+            raise RuntimeError("rth_render_like_main: " + host().rth_last_error().decode())
+        return out, st
+
+    def close(self):
+        if self._h:
+            host().rth_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def bvh_build(bounds):
+    bounds = np.ascontiguousarray(bounds, np.float32).reshape(-1, 6)
+    n = bounds.shape[0]
+    nodes = np.zeros(max(2 * n, 1), BVH_NODE_DTYPE)
+    order = np.zeros(max(n, 1), np.int32)
+    nn = C.c_int32(0)
+    rc = rt().rt_bvh_build(n, capi.fptr(bounds), nodes.ctypes.data_as(C.POINTER(capi.BvhNode)), C.byref(nn), capi.iptr(order))
+    if rc != 0:
+        raise RuntimeError("rt_bvh_build failed")
+    return nodes[:nn.value].copy(), order[:n].copy()
+
+
+def prim_bounds(desc_ptr):
+    n = desc_ptr.contents.n_prims
+    out = np.zeros((n, 6), np.float32)
+    if rt().rt_prim_bounds(desc_ptr, capi.fptr(out)) != 0:
+        raise RuntimeError("rt_prim_bounds failed")
+    return out
+
+
+def tonemap_u8(sum_rgb, spp):
+    sum_rgb = np.ascontiguousarray(sum_rgb, np.float32)
+    h, w = sum_rgb.shape[:2]
+    out = np.zeros((h, w, 3), np.uint8)
+    if rt().rt_tonemap_u8(capi.fptr(sum_rgb), w, h, spp, capi.u8ptr(out)) != 0:
+        raise RuntimeError("rt_tonemap_u8 failed")
+    return out
+
+
+def make_opts(sx, sy, begin=0, end=None, max_depth=50, seed=(0x243F6A88, 0x85A308D3), pool_paths=0, flags=0):
+    o = RenderOpts()
+    o.strata_x, o.strata_y = sx, sy
+    o.sample_begin, o.sample_end = begin, (sx * sy if end is None else end)
+    o.max_depth = max_depth
+    o.seed_lo, o.seed_hi = seed
+    o.pool_paths = pool_paths
+    o.flags = flags
+    return o
+
+
+class Context:
+    """rt_ctx: one per process, bound to one HIP device."""
+
+    def __init__(self, device=0):
+        self._p = C.c_void_p()
+        rc = rt().rt_init(device, C.byref(self._p))
+        if rc != 0:
+            raise RuntimeError("rt_init failed: %s" % rt().rt_last_error(None).decode())
+
+    def error(self):
+        return rt().rt_last_error(self._p).decode()
+
+    def close(self):
+        if self._p:
+            rt().rt_shutdown(self._p)
+            self._p = C.c_void_p()
+
+
+class DeviceScene:
+    """rt_scene: a flattened scene resident in HBM."""
+
+    def __init__(self, ctx, desc_ptr):
+        self.ctx = ctx
+        self._p = C.c_void_p()
+        if rt().rt_scene_create(ctx._p, desc_ptr, C.byref(self._p)) != 0:
+            raise RuntimeError("rt_scene_create: " + ctx.error())
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s: %s" % (what, self.ctx.error()))
+
+    def get_bvh(self, n_prims):
+        nn = C.c_int32(0)
+        self._chk(rt().rt_scene_get_bvh(self._p, None, C.byref(nn), None), "rt_scene_get_bvh")
+        nodes = np.zeros(nn.value, BVH_NODE_DTYPE)
+        order = np.zeros(n_prims, np.int32)
+        self._chk(rt().rt_scene_get_bvh(self._p, nodes.ctypes.data_as(C.POINTER(capi.BvhNode)), C.byref(nn), capi.iptr(order)),
+                  "rt_scene_get_bvh")
+        return nodes, order
+
+    def trace_closest(self, o, d, tmax):
+        o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        n = o.shape[0]
+        prim = np.zeros(n, np.int32); t = np.zeros(n, np.float32); b = np.zeros((n, 2), np.float32)
+        self._chk(rt().rt_trace_closest(self._p, n, capi.fptr(o), capi.fptr(d), capi.fptr(tmax), capi.iptr(prim), capi.fptr(t),
+                                        capi.fptr(b)), "rt_trace_closest")
+        return prim, t, b
+
+    def trace_any(self, o, d, tmax):
+        o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        n = o.shape[0]
+        hit = np.zeros(n, np.uint8)
+        self._chk(rt().rt_trace_any(self._p, n, capi.fptr(o), capi.fptr(d), capi.fptr(tmax), capi.u8ptr(hit)), "rt_trace_any")
+        return hit
+
+    def trace_closest_device(self, n, rays_ptr, hits_ptr, repeats=1, count_work=False):
+        st = TraceStats()
+        self._chk(rt().rt_trace_closest_device(self._p, n, C.c_void_p(rays_ptr), C.c_void_p(hits_ptr), repeats, int(count_work),
+                                               C.byref(st)), "rt_trace_closest_device")
+        return st
+
+    def render(self, cam, opts):
+        out = np.zeros((cam.height, cam.width, 3), np.float32)
+        st = RenderStats()
+        self._chk(rt().rt_render(self._p, C.byref(cam), C.byref(opts), capi.fptr(out), C.byref(st)), "rt_render")
+        return out, st
+
+    def render_device(self, cam, opts):
+        ptr = C.c_void_p()
+        st = RenderStats()
+        self._chk(rt().rt_render_device(self._p, C.byref(cam), C.byref(opts), C.byref(ptr), C.byref(st)), "rt_render_device")
+        return ptr.value, st
+
+    def close(self):
+        if self._p:
+            rt().rt_scene_destroy(self._p)
+            self._p = C.c_void_p()

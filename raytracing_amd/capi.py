@@ -1,0 +1,143 @@
+"""ctypes mirror of include/rt_amd.h and of the host-surface helper API (raytracing_amd/host/scenes.cpp).
+
+Everything here goes through the two in-tree shared libraries; there is no Python or CPU
+implementation of the path behind it.  Importing fails loudly when a library is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+
+
+class BvhNode(C.Structure):
+    _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("offset", C.c_int32),
+                ("nprim", C.c_uint16), ("axis", C.c_uint8), ("pad", C.c_uint8)]
+
+
+BVH_NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4"),
+                           ("nprim", "<u2"), ("axis", "u1"), ("pad", "u1")])
+assert BVH_NODE_DTYPE.itemsize == 32 and C.sizeof(BvhNode) == 32
+
+
+class Sphere(C.Structure):
+    _fields_ = [("radius", C.c_float), ("o2w", C.c_float * 16), ("w2o", C.c_float * 16)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("value", C.c_float * 3),
+                ("texels", C.POINTER(C.c_float)), ("su", C.c_float), ("sv", C.c_float), ("du", C.c_float), ("dv", C.c_float)]
+
+
+class Material(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("tex", C.c_int32 * 4), ("remap_roughness", C.c_int32), ("pad", C.c_int32)]
+
+
+class Light(C.Structure):
+    _fields_ = [("prim", C.c_int32), ("Le", C.c_float * 3), ("two_sided", C.c_int32), ("area", C.c_float)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("n_prims", C.c_int32), ("prim_kind", C.POINTER(C.c_uint8)), ("prim_geom", C.POINTER(C.c_int32)),
+        ("prim_material", C.POINTER(C.c_int32)), ("prim_light", C.POINTER(C.c_int32)),
+        ("n_tris", C.c_int32), ("tri_p", C.POINTER(C.c_float)), ("tri_uv", C.POINTER(C.c_float)),
+        ("tri_n", C.POINTER(C.c_float)), ("tri_has_n", C.POINTER(C.c_uint8)),
+        ("n_spheres", C.c_int32), ("spheres", C.POINTER(Sphere)),
+        ("n_materials", C.c_int32), ("materials", C.POINTER(Material)),
+        ("n_textures", C.c_int32), ("textures", C.POINTER(Texture)),
+        ("n_lights", C.c_int32), ("lights", C.POINTER(Light)),
+        ("n_nodes", C.c_int32), ("bvh_nodes", C.POINTER(BvhNode)), ("prim_order", C.POINTER(C.c_int32)),
+    ]
+
+
+class Camera(C.Structure):
+    _fields_ = [("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class RenderOpts(C.Structure):
+    _fields_ = [("strata_x", C.c_int32), ("strata_y", C.c_int32), ("sample_begin", C.c_int32), ("sample_end", C.c_int32),
+                ("max_depth", C.c_int32), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
+                ("pool_paths", C.c_int32), ("flags", C.c_int32)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64), ("iterations", C.c_uint64),
+                ("seconds_total", C.c_double), ("seconds_trace", C.c_double), ("seconds_shade", C.c_double),
+                ("seconds_shadow", C.c_double)]
+
+
+class TraceStats(C.Structure):
+    _fields_ = [("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64), ("seconds", C.c_double)]
+
+
+RT_RENDER_ACCUMULATE = 1
+
+# Every symbol include/rt_amd.h declares.
+RT_AMD_SYMBOLS = [
+    "rt_version", "rt_init", "rt_shutdown", "rt_last_error", "rt_bvh_build", "rt_prim_bounds", "rt_scene_create",
+    "rt_scene_destroy", "rt_scene_get_bvh", "rt_trace_closest", "rt_trace_any", "rt_trace_closest_device",
+    "rt_render", "rt_render_device", "rt_tonemap_u8",
+]
+
+
+def _load(name):
+    path = os.path.join(LIB_DIR, name)
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no fallback implementation)")
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+def load_rt_amd():
+    lib = _load("librt_amd.so")
+    vp, i32p, f32p, u8p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+    lib.rt_version.restype = C.c_char_p
+    lib.rt_init.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.rt_shutdown.argtypes = [vp]; lib.rt_shutdown.restype = None
+    lib.rt_last_error.argtypes = [vp]; lib.rt_last_error.restype = C.c_char_p
+    lib.rt_bvh_build.argtypes = [C.c_int32, f32p, C.POINTER(BvhNode), i32p, i32p]
+    lib.rt_prim_bounds.argtypes = [C.POINTER(SceneDesc), f32p]
+    lib.rt_scene_create.argtypes = [vp, C.POINTER(SceneDesc), C.POINTER(vp)]
+    lib.rt_scene_destroy.argtypes = [vp]; lib.rt_scene_destroy.restype = None
+    lib.rt_scene_get_bvh.argtypes = [vp, C.POINTER(BvhNode), i32p, i32p]
+    lib.rt_trace_closest.argtypes = [vp, C.c_size_t, f32p, f32p, f32p, i32p, f32p, f32p]
+    lib.rt_trace_any.argtypes = [vp, C.c_size_t, f32p, f32p, f32p, u8p]
+    lib.rt_trace_closest_device.argtypes = [vp, C.c_size_t, vp, vp, C.c_int, C.c_int, C.POINTER(TraceStats)]
+    lib.rt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderOpts), f32p, C.POINTER(RenderStats)]
+    lib.rt_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderOpts), C.POINTER(vp), C.POINTER(RenderStats)]
+    lib.rt_tonemap_u8.argtypes = [f32p, C.c_int32, C.c_int32, C.c_int32, u8p]
+    return lib
+
+
+def load_rt_host():
+    load_rt_amd()
+    lib = _load("librt_host.so")
+    vp = C.c_void_p
+    lib.rth_last_error.restype = C.c_char_p
+    lib.rth_scene_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int64]; lib.rth_scene_build.restype = vp
+    lib.rth_scene_desc.argtypes = [vp]; lib.rth_scene_desc.restype = C.POINTER(SceneDesc)
+    lib.rth_scene_camera.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Camera)]
+    lib.rth_scene_free.argtypes = [vp]; lib.rth_scene_free.restype = None
+    lib.rth_register_image.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint8)]; lib.rth_register_image.restype = None
+    lib.rth_render_like_main.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
+                                         C.POINTER(C.c_float), C.POINTER(RenderStats)]
+    lib.rth_kat_transform.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.rth_kat_camera.argtypes = [C.POINTER(C.c_float)] * 3 + [C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(Camera)]
+    return lib
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def u8ptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))

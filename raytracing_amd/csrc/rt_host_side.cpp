@@ -1,0 +1,145 @@
+// rt_host_side.cpp — the entry points of rt_amd.h that run on the host and need no GPU:
+// rt_bvh_build, rt_prim_bounds, rt_tonemap_u8, rt_version.
+#include "rt_amd.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace {
+
+// One primitive during the build: centroid for the split decisions, id to find its box again.
+struct Item { float c[3]; int32_t id; };
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() {
+        for (int k = 0; k < 3; ++k) { lo[k] = std::numeric_limits<float>::max(); hi[k] = std::numeric_limits<float>::lowest(); }
+    }
+    void grow(const float *p) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } }
+    void grow(const Box &b) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); } }
+};
+
+// Emits the linear tree directly in depth-first pre-order (a node's first child is the
+// next node), which is the layout flattenBVHTree produces (bvh.cpp:229-245).  The split
+// rule is recursiveBuild's SplitMethod::Middle with its fall-through to EqualCounts
+// (bvh.cpp:105-141); node boxes are unions of the children's boxes, which equals the
+// reference's loop over the range because min/max never round.  Leaf slots are handed out
+// in depth-first order.
+struct TreeEmitter {
+    std::vector<Item> items;
+    const float *bounds;   // n*6
+    rt_bvh_node *nodes;
+    int32_t *order;
+    int32_t nNodes = 0, nSlots = 0;
+
+    Box emit(int start, int end) {
+        int32_t me = nNodes++;
+        rt_bvh_node &node = nodes[me];
+        std::memset(&node, 0, sizeof(node));
+        int count = end - start;
+        Box cb; cb.reset();
+        for (int i = start; i < end; ++i) cb.grow(items[i].c);
+        float dx = cb.hi[0] - cb.lo[0], dy = cb.hi[1] - cb.lo[1], dz = cb.hi[2] - cb.lo[2];
+        int dim = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);   // Bounds3::MaximumExtent, geometry.h:780-788
+        Box box;
+        if (count == 1 || cb.hi[dim] == cb.lo[dim]) {
+            box.reset();
+            node.offset = nSlots; node.nprim = (uint16_t)count;
+            for (int i = start; i < end; ++i) {
+                const float *b = bounds + 6 * (size_t)items[i].id;
+                box.grow(b); box.grow(b + 3);
+                order[nSlots++] = items[i].id;
+            }
+        } else {
+            float pmid = (cb.lo[dim] + cb.hi[dim]) / 2;
+            Item *first = items.data() + start, *last = items.data() + end;
+            Item *m = std::partition(first, last, [dim, pmid](const Item &it) { return it.c[dim] < pmid; });
+            int mid = (int)(m - items.data());
+            if (mid == start || mid == end) {
+                mid = (start + end) / 2;
+                std::nth_element(first, items.data() + mid, last, [dim](const Item &a, const Item &b) { return a.c[dim] < b.c[dim]; });
+            }
+            box = emit(start, mid);
+            int32_t second = nNodes;
+            Box right = emit(mid, end);
+            box.grow(right);
+            rt_bvh_node &self = nodes[me];   // `node` may dangle only if nodes were reallocated; they are not, but stay explicit
+            self.offset = second; self.nprim = 0; self.axis = (uint8_t)dim;
+        }
+        rt_bvh_node &self = nodes[me];
+        for (int k = 0; k < 3; ++k) { self.bmin[k] = box.lo[k]; self.bmax[k] = box.hi[k]; }
+        return box;
+    }
+};
+
+inline void xf_point(const float *m, float x, float y, float z, float *out) {   // Transform::operator()(Point3f), transform.h:135-146
+    float xp = m[0] * x + m[1] * y + m[2] * z + m[3];
+    float yp = m[4] * x + m[5] * y + m[6] * z + m[7];
+    float zp = m[8] * x + m[9] * y + m[10] * z + m[11];
+    float wp = m[12] * x + m[13] * y + m[14] * z + m[15];
+    if (wp == 1) { out[0] = xp; out[1] = yp; out[2] = zp; }
+    else { float inv = 1.f / wp; out[0] = inv * xp; out[1] = inv * yp; out[2] = inv * zp; }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_version(void) { return "raytracing_amd 0.1 (gfx950)"; }
+
+int rt_bvh_build(int32_t n, const float *prim_bounds, rt_bvh_node *nodes_out, int32_t *n_nodes_out, int32_t *order_out) {
+    if (n < 0 || (n > 0 && (!prim_bounds || !nodes_out || !order_out)) || !n_nodes_out) return -1;
+    if (n == 0) { *n_nodes_out = 0; return 0; }
+    TreeEmitter te;
+    te.items.resize(n);
+    for (int32_t i = 0; i < n; ++i) {
+        const float *b = prim_bounds + 6 * (size_t)i;
+        for (int k = 0; k < 3; ++k) te.items[i].c[k] = .5f * b[k] + .5f * b[3 + k];   // bvh.cpp:14
+        te.items[i].id = i;
+    }
+    te.bounds = prim_bounds; te.nodes = nodes_out; te.order = order_out;
+    te.emit(0, n);
+    *n_nodes_out = te.nNodes;
+    return 0;
+}
+
+int rt_prim_bounds(const rt_scene_desc *d, float *out) {
+    if (!d || !out) return -1;
+    for (int32_t i = 0; i < d->n_prims; ++i) {
+        Box b; b.reset();
+        if (d->prim_kind[i] == RT_PRIM_TRIANGLE) {
+            const float *p = d->tri_p + 9 * (size_t)d->prim_geom[i];
+            b.grow(p); b.grow(p + 3); b.grow(p + 6);
+        } else {
+            // Shape::WorldBound = ObjectToWorld(ObjectBound): the 8 transformed corners (transform.cpp:181-192)
+            const rt_sphere &s = d->spheres[d->prim_geom[i]];
+            float r = s.radius;
+            for (int corner = 0; corner < 8; ++corner) {
+                float q[3];
+                xf_point(s.o2w, (corner & 1) ? r : -r, (corner & 2) ? r : -r, (corner & 4) ? r : -r, q);
+                b.grow(q);
+            }
+        }
+        for (int k = 0; k < 3; ++k) { out[6 * (size_t)i + k] = b.lo[k]; out[6 * (size_t)i + 3 + k] = b.hi[k]; }
+    }
+    return 0;
+}
+
+int rt_tonemap_u8(const float *sum_rgb, int32_t width, int32_t height, int32_t spp, uint8_t *out_rgb) {
+    if (!sum_rgb || !out_rgb || width <= 0 || height <= 0 || spp <= 0) return -1;
+    size_t n = (size_t)width * height * 3;
+    float fspp = (float)spp;
+    for (size_t i = 0; i < n; ++i) {
+        float v = sum_rgb[i] / fspp;                 // colObj / samplesPerPixel, integrator.cpp:337
+        if (v != v) v = 0.f;                         // NaN -> 0, integrator.cpp:294-296
+        v = (float)std::sqrt((double)v);             // gamma 2 through a double sqrt, integrator.cpp:299-302
+        float c = v < 0.f ? 0.f : (v > 0.999f ? 0.999f : v);
+        out_rgb[i] = (uint8_t)(int)(256 * c);
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,994 @@
+// rt_kernels.hip — HIP kernels of the wavefront path tracer and the GPU half of the C ABI (rt_amd.h).
+//
+// Pipeline for one pass over N = pixels x samples-in-pass camera paths (all state stays in HBM):
+//   k_raygen            camera rays, Philox film jitter                       camera.cpp:52-58, stratified.cpp:4-29
+//   per bounce b = 0..maxDepth:
+//     k_extend          closest-hit BVH traversal + path logic (emission, sky, termination),
+//                       appends the path to the queue of its material class     bvh.cpp:247-282, integrator.cpp:241-257
+//     k_shade<MAT>      one launch per material class present in the scene: BSDF build, next-event
+//                       estimation (-> compacted shadow queue), BSDF sampling, Russian roulette
+//                       (-> compacted next-bounce queue)                      integrator.cpp:258-280, material.cpp, reflection.cpp
+//     k_shadow          any-hit traversal of the shadow queue, adds unoccluded light  bvh.cpp:284-320, light.cpp:19-21
+//   k_accumulate        per-pixel sum of the pass's path radiances into the frame's sum buffer  integrator.cpp:324-337
+// Queues are compacted with wave ballots + one atomic per wave; no scattered float atomics are used:
+// every path owns one float4 slot of radiance that only its own lane updates.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "rt_amd.h"
+#include "rt_device.h"
+
+#define HIP_OK(expr)                                                                                        \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) { set_error(ctx_of(this_), std::string(#expr) + ": " + hipGetErrorString(e_)); return -2; } \
+    } while (0)
+
+#define RT_NUM_CLASSES 6
+#define RT_COUNTER_WORDS 32
+
+// Per-bounce device counters (all zeroed once per pass).
+struct BounceCounters {
+    uint32_t n_queue;                   // paths entering this bounce
+    uint32_t n_shadow;                  // shadow rays produced by this bounce
+    uint32_t cls[RT_NUM_CLASSES];       // paths per material class
+    uint32_t fetch_extend, fetch_shadow;
+    uint32_t fetch_cls[RT_NUM_CLASSES];
+    uint32_t stack_overflow;
+    uint32_t pad[RT_COUNTER_WORDS - 5 - 2 * RT_NUM_CLASSES];
+};
+static_assert(sizeof(BounceCounters) == RT_COUNTER_WORDS * 4, "counter block size");
+
+struct PathQueue {   // SoA, capacity = cap
+    float *ox, *oy, *oz, *dx, *dy, *dz, *tr, *tg, *tb;
+    uint32_t *id, *state;   // state: depth | specular << 16
+};
+struct HitBuf { int *slot; float *t, *b0, *b1, *b2; };
+struct ShadowQueue { uint32_t *id; float *ox, *oy, *oz, *dx, *dy, *dz, *cr, *cg, *cb; };
+
+struct RenderParams {
+    float r2c[16], c2w[16];
+    int width, height;
+    int strata_x, strata_y;
+    int spb;            // samples of each pixel in this pass
+    int sample0;        // first sample index of this pass
+    int max_depth;
+    uint32_t k0, k1;
+    uint32_t n_paths;
+};
+
+// ---------------------------------------------------------------- helpers --
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t prefix_in_mask(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// Wave-aggregated append: every lane with `want` gets a unique position in a queue whose size lives at *counter.
+__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t *counter) {
+    uint64_t mask = __ballot(want);
+    if (mask == 0) return 0;
+    uint32_t n = __popcll(mask), base = 0;
+    int leader = __ffsll((unsigned long long)mask) - 1;
+    if ((int)lane_id() == leader) base = atomicAdd(counter, n);
+    base = __shfl(base, leader);
+    return base + prefix_in_mask(mask);
+}
+// Each wave of a persistent grid takes the next 64 work items.
+__device__ __forceinline__ uint32_t wave_fetch(uint32_t *fetch) {
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(fetch, RT_WAVE);
+    return __builtin_amdgcn_readfirstlane(base);
+}
+
+// ----------------------------------------------------- batch trace kernels --
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_batch(DevScene sc, size_t n, const float *__restrict__ rays, int aos, int *out_prim, float *out_t,
+                                                           float *out_b1, float *out_b2, uint8_t *out_any, int *spill, unsigned long long *work) {
+    __shared__ int s_stack[RT_LDS_STACK * RT_BLOCK];
+    size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    TravStack st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.sp = 0;
+    uint32_t nNodes = 0, nTests = 0;
+    for (size_t i = gtid; i < n; i += nthreads) {
+        F3 o, d; float tmax;
+        if (aos) { o = f3(rays[7 * i], rays[7 * i + 1], rays[7 * i + 2]); d = f3(rays[7 * i + 3], rays[7 * i + 4], rays[7 * i + 5]); tmax = rays[7 * i + 6]; }
+        else { o = f3(rays[i], rays[n + i], rays[2 * n + i]); d = f3(rays[3 * n + i], rays[4 * n + i], rays[5 * n + i]); tmax = rays[6 * n + i]; }
+        HitRec h;
+        bool found = traverse<ANY, COUNT>(sc, o, d, tmax, st, h, nNodes, nTests);
+        if (ANY) out_any[i] = found ? 1 : 0;
+        else {
+            int prim = -1; float b1 = h.b1, b2 = h.b2;
+            if (found) {
+                float4 r2 = sc.slots[3 * h.slot + 2];
+                prim = __float_as_int(r2.z);
+                if (__float_as_uint(r2.y) & RT_SLOT_SPHERE) {   // (u, v) of the hit, sphere.cpp:51-58
+                    const float *sp = sc.spheres + 32 * (size_t)__float_as_int(r2.w);
+                    F3 oo = xf_point(sp + 4, o), dd = xf_vector(sp + 4, d);
+                    F3 ph = oo + h.t * dd;
+                    float phi = atan2f(ph.y, ph.x);
+                    if (phi < 0) phi += 2 * RT_PI;
+                    b1 = phi / (2 * RT_PI);
+                    b2 = acosf(clampf(ph.z / sp[0], -1.f, 1.f)) / RT_PI;
+                }
+            }
+            out_prim[i] = prim; out_t[i] = h.t;
+            if (out_b1) { out_b1[i] = b1; out_b2[i] = b2; }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&work[0], (unsigned long long)nNodes);
+        atomicAdd(&work[1], (unsigned long long)nTests);
+    }
+}
+
+// ------------------------------------------------------------------ raygen --
+// Film sample = stratum (Kensler permutation of the sample index, keyed per pixel) + Philox jitter;
+// ray = PerspectiveCamera::GenerateRay (camera.cpp:52-58).
+__device__ __forceinline__ F3 xf_point_proj(const float *m, F3 p) {   // Transform::operator()(Point3f) with the w divide, transform.h:135-146
+    float xp = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    float yp = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    float zp = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    float wp = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    if (wp == 1) return f3(xp, yp, zp);
+    float inv = 1.f / wp;
+    return f3(inv * xp, inv * yp, inv * zp);
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderParams rp, PathQueue q, float4 *lbuf, BounceCounters *counters) {
+    uint32_t n = rp.n_paths;
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < n; id += gridDim.x * blockDim.x) {
+        uint32_t pixel = id / (uint32_t)rp.spb, sample = (uint32_t)rp.sample0 + id % (uint32_t)rp.spb;
+        uint32_t c0 = pixel, c1 = sample, c2 = 0xFFFFFFFFu, c3 = 0;
+        philox4x32(c0, c1, c2, c3, rp.k0, rp.k1);
+        uint32_t p0 = pixel, p1 = 0xFFFFFFFFu, p2 = 0xFFFFFFFFu, p3 = 0;
+        philox4x32(p0, p1, p2, p3, rp.k0, rp.k1);
+        uint32_t nstrata = (uint32_t)(rp.strata_x * rp.strata_y);
+        uint32_t s = kensler_permute(sample % nstrata, nstrata, p0);
+        int sx = (int)(s % (uint32_t)rp.strata_x), sy = (int)(s / (uint32_t)rp.strata_x);
+        float ddx = 1.f / rp.strata_x, ddy = 1.f / rp.strata_y;
+        float fx = fminf((sx + u32_to_unit(c0)) * ddx, RT_ONE_MINUS_EPS), fy = fminf((sy + u32_to_unit(c1)) * ddy, RT_ONE_MINUS_EPS);
+        int px = (int)(pixel % (uint32_t)rp.width), py = (int)(pixel / (uint32_t)rp.width);
+        F3 pCamera = xf_point_proj(rp.r2c, f3((float)px + fx, (float)py + fy, 0.f));
+        F3 dir = normalize3(pCamera);
+        F3 o = xf_point_proj(rp.c2w, f3(0.f, 0.f, 0.f));
+        F3 d = xf_vector(rp.c2w, dir);
+        q.ox[id] = o.x; q.oy[id] = o.y; q.oz[id] = o.z; q.dx[id] = d.x; q.dy[id] = d.y; q.dz[id] = d.z;
+        q.tr[id] = 1.f; q.tg[id] = 1.f; q.tb[id] = 1.f; q.id[id] = id; q.state[id] = 0;
+        lbuf[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[0].n_queue = n;
+}
+
+// ------------------------------------------------------------------ extend --
+__global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
+                                                      float4 *lbuf, BounceCounters *counters, int *spill) {
+    __shared__ int s_stack[RT_LDS_STACK * RT_BLOCK];
+    BounceCounters *bc = counters + bounce;
+    const uint32_t n = bc->n_queue;
+    size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    TravStack st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.sp = 0;
+    uint32_t lane = lane_id();
+    while (true) {
+        uint32_t base = wave_fetch(&bc->fetch_extend);
+        if (base >= n) break;
+        uint32_t i = base + lane;
+        bool active = i < n;
+        int cls = -1;
+        if (active) {
+            F3 o = f3(q.ox[i], q.oy[i], q.oz[i]), d = f3(q.dx[i], q.dy[i], q.dz[i]);
+            uint32_t state = q.state[i];
+            int depth = state & 0xFFFF; bool spec = (state >> 16) & 1;
+            HitRec h; uint32_t c0 = 0, c1 = 0;
+            bool found = traverse<false, false>(sc, o, d, RT_INF, st, h, c0, c1);
+            hb.slot[i] = h.slot; hb.t[i] = h.t; hb.b0[i] = h.b0; hb.b1[i] = h.b1; hb.b2[i] = h.b2;
+            // integrator.cpp:242-257
+            F3 add = f3(0.f, 0.f, 0.f); bool terminal = false;
+            if (depth == 0 || spec || sc.n_lights == 0) {
+                if (found) {
+                    int li = sc.slot_light[h.slot];
+                    if (li >= 0) {
+                        const DevLight &L = sc.lights[li];
+                        float4 nf = sc.frames[3 * h.slot];
+                        if (L.two_sided || dot3(f3(nf.x, nf.y, nf.z), -d) > 0) add = f3(L.Le[0], L.Le[1], L.Le[2]);   // light.h:73-75
+                        if (!black3(add)) terminal = true;
+                    }
+                } else if (sc.n_lights == 0) {
+                    F3 ud = normalize3(d);
+                    double t = 0.5 * (ud.y + 1.0);
+                    float a = (float)(1.0 - t), b = (float)t;
+                    add = f3(1.0f * a + 0.5f * b, 1.0f * a + 0.7f * b, 1.0f * a + 1.0f * b);
+                }
+            }
+            if (!found || depth >= rp.max_depth) terminal = true;
+            if (!black3(add)) {
+                uint32_t id = q.id[i];
+                float4 L = lbuf[id];
+                L.x += q.tr[i] * add.x; L.y += q.tg[i] * add.y; L.z += q.tb[i] * add.z;
+                lbuf[id] = L;
+            }
+            if (!terminal) cls = sc.materials[sc.slot_material[h.slot]].kind;
+        }
+        // append to the queue of the material class (counting-sort style binning, one ballot per class present)
+        for (int c = 0; c < RT_NUM_CLASSES; ++c) {
+            bool mine = (cls == c);
+            if (__ballot(mine) == 0) continue;
+            uint32_t pos = wave_append(mine, &bc->cls[c]);
+            if (mine) cls_list[(size_t)c * cap + pos] = i;
+        }
+    }
+}
+
+// ------------------------------------------------------------------- shade --
+struct SurfacePoint { F3 p, n, ss, ts, wo; float u, v; };
+
+// Interaction at the hit: Triangle::Intersect triangle.cpp:121-146 (frame precomputed per triangle on the host),
+// Sphere::Intersect sphere.cpp:51-70 + Transform::operator()(SurfaceInteraction) transform.cpp:205-235.
+__device__ __forceinline__ void surface_point(const DevScene &sc, int slot, F3 o, F3 d, float t, float b0, float b1, float b2, bool need_uv, SurfacePoint &sp) {
+    float4 r0 = sc.slots[3 * slot], r1 = sc.slots[3 * slot + 1], r2 = sc.slots[3 * slot + 2];
+    if (__float_as_uint(r2.y) & RT_SLOT_SPHERE) {
+        const float *s = sc.spheres + 32 * (size_t)__float_as_int(r2.w);
+        F3 oo = xf_point(s + 4, o), dd = xf_vector(s + 4, d);
+        F3 ph = oo + t * dd;
+        if (need_uv) {
+            float phi = atan2f(ph.y, ph.x);
+            if (phi < 0) phi += 2 * RT_PI;
+            sp.u = phi / (2 * RT_PI);
+            sp.v = acosf(clampf(ph.z / s[0], -1.f, 1.f)) / RT_PI;
+        } else { sp.u = sp.v = 0.f; }
+        float phiMax = 2 * RT_PI;
+        F3 dpdu = f3(-phiMax * ph.y, phiMax * ph.x, 0.f);
+        F3 n1 = normalize3(ph);
+        sp.p = xf_point(s + 16, ph);
+        sp.wo = normalize3(xf_vector(s + 16, -dd));
+        sp.n = xf_normal_by_inverse(s + 4, n1);
+        sp.ss = normalize3(xf_vector(s + 16, dpdu));
+        sp.ts = cross3(sp.n, sp.ss);
+    } else {
+        F3 p0 = f3(r0.x, r0.y, r0.z), p1 = f3(r0.w, r1.x, r1.y), p2 = f3(r1.z, r1.w, r2.x);
+        sp.p = (b0 * p0 + b1 * p1) + b2 * p2;
+        float4 fn = sc.frames[3 * slot], fs = sc.frames[3 * slot + 1], ft = sc.frames[3 * slot + 2];
+        sp.n = f3(fn.x, fn.y, fn.z); sp.ss = f3(fs.x, fs.y, fs.z); sp.ts = f3(ft.x, ft.y, ft.z);
+        sp.wo = -d;
+        if (need_uv) {
+            const float *uv = sc.slot_uv + 6 * (size_t)slot;
+            sp.u = (b0 * uv[0] + b1 * uv[2]) + b2 * uv[4];
+            sp.v = (b0 * uv[1] + b1 * uv[3]) + b2 * uv[5];
+        } else { sp.u = sp.v = 0.f; }
+    }
+}
+__device__ __forceinline__ F3 to_local(const SurfacePoint &sp, F3 v) { return f3(dot3(v, sp.ss), dot3(v, sp.ts), dot3(v, sp.n)); }
+__device__ __forceinline__ F3 to_world(const SurfacePoint &sp, F3 v) {
+    return f3(sp.ss.x * v.x + sp.ts.x * v.y + sp.n.x * v.z, sp.ss.y * v.x + sp.ts.y * v.y + sp.n.y * v.z, sp.ss.z * v.x + sp.ts.z * v.y + sp.n.z * v.z);
+}
+
+// One scattering lobe of the hit's BSDF (the shipped materials have exactly one, material.cpp:5-82).
+struct Lobe {
+    int kind;        // 0 none, 1 Lambert, 2 specular reflection, 3 specular transmission, 4 microfacet conductor, 5 metal-roughness
+    F3 R, eta, k;
+    float etaB, metallic;
+    TRDist dist;
+};
+__device__ __forceinline__ bool lobe_is_specular(int kind) { return kind == 2 || kind == 3; }
+
+// BxDF::f in the local frame: reflection.cpp:135-137, 241-249, 268-284.
+__device__ __forceinline__ F3 lobe_f(const Lobe &l, F3 wo, F3 wi) {
+    if (l.kind == 1) return f3(l.R.x * RT_INV_PI, l.R.y * RT_INV_PI, l.R.z * RT_INV_PI);
+    if (l.kind == 4 || l.kind == 5) {
+        float cosO = fabsf(wo.z), cosI = fabsf(wi.z);
+        F3 wh = wi + wo;
+        if (cosI == 0 || cosO == 0) return f3(0.f, 0.f, 0.f);
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) return f3(0.f, 0.f, 0.f);
+        wh = normalize3(wh);
+        F3 whf = (wh.z < 0.f) ? -wh : wh;   // Faceforward(wh, (0,0,1))
+        float c = dot3(wi, whf);
+        float Dv = l.dist.D(wh), Gv = l.dist.G(wo, wi);
+        if (l.kind == 4) {
+            float ca = fabsf(c);
+            F3 F = f3(fr_conductor1(ca, l.eta.x, l.k.x), fr_conductor1(ca, l.eta.y, l.k.y), fr_conductor1(ca, l.eta.z, l.k.z));
+            float den = 4 * cosI * cosO;
+            return cdiv(f3(((l.R.x * Dv) * Gv) * F.x, ((l.R.y * Dv) * Gv) * F.y, ((l.R.z * Dv) * Gv) * F.z), den);
+        }
+        float cs = fabsf(c);
+        float om = 1 - l.metallic;
+        F3 F0 = f3(0.04f * om + l.R.x * l.metallic, 0.04f * om + l.R.y * l.metallic, 0.04f * om + l.R.z * l.metallic);
+        double x = 1.0 - (double)cs, x2 = x * x;
+        float p5 = (float)(x2 * x2 * x);
+        F3 F = f3(F0.x + (1.0f - F0.x) * p5, F0.y + (1.0f - F0.y) * p5, F0.z + (1.0f - F0.z) * p5);
+        float dg = Dv * Gv;
+        float den = (float)((double)(4 * cosI * cosO) + 0.001);
+        F3 spec = cdiv(f3(F.x * dg, F.y * dg, F.z * dg), den);
+        float km = (float)(1.0 - (double)l.metallic);
+        F3 kD = f3((1.0f - F.x) * km, (1.0f - F.y) * km, (1.0f - F.z) * km);
+        return f3(spec.x + (kD.x * l.R.x) * RT_INV_PI, spec.y + (kD.y * l.R.y) * RT_INV_PI, spec.z + (kD.z * l.R.z) * RT_INV_PI);
+    }
+    return f3(0.f, 0.f, 0.f);
+}
+
+// BxDF::Sample_f in the local frame: reflection.cpp:99-105 (Lambert), 62-68 (mirror, FresnelNoOp),
+// 75-88 (glass, Radiance mode), 251-260 / 286-294 (microfacet lobes).  pdf == 0 means "no sample".
+__device__ __forceinline__ F3 lobe_sample(const Lobe &l, F3 wo, float u0, float u1, F3 &wi, float &pdf) {
+    pdf = 0.f;
+    if (l.kind == 1) {
+        wi = cosine_sample_hemisphere(u0, u1);
+        if (wo.z < 0) wi.z *= -1;
+        pdf = same_hemisphere(wo, wi) ? fabsf(wi.z) * RT_INV_PI : 0.f;
+        return lobe_f(l, wo, wi);
+    }
+    if (l.kind == 2) {
+        wi = f3(-wo.x, -wo.y, wo.z);
+        pdf = 1;
+        return cdiv(f3(1.f * l.R.x, 1.f * l.R.y, 1.f * l.R.z), fabsf(wi.z));
+    }
+    if (l.kind == 3) {
+        bool entering = wo.z > 0;
+        float etaI = entering ? 1.f : l.etaB, etaT = entering ? l.etaB : 1.f;
+        F3 n = (wo.z < 0.f) ? f3(-0.f, -0.f, -1.f) : f3(0.f, 0.f, 1.f);   // Faceforward(Normal3f(0,0,1), wo)
+        float eta = etaI / etaT;
+        float cosThetaI = dot3(n, wo);                                   // Refract, reflection.h:52-61
+        float sin2ThetaI = fmaxf(0.f, 1 - cosThetaI * cosThetaI);
+        float sin2ThetaT = eta * eta * sin2ThetaI;
+        if (sin2ThetaT >= 1) return f3(0.f, 0.f, 0.f);
+        float cosThetaT = sqrtf(1 - sin2ThetaT);
+        wi = eta * (-wo) + (eta * cosThetaI - cosThetaT) * n;
+        pdf = 1;
+        float fr = fr_dielectric(wi.z, 1.f, l.etaB);
+        F3 ft = f3(l.R.x * (1.f - fr), l.R.y * (1.f - fr), l.R.z * (1.f - fr));
+        float sc = (etaI * etaI) / (etaT * etaT);
+        ft = f3(ft.x * sc, ft.y * sc, ft.z * sc);
+        return cdiv(ft, fabsf(wi.z));
+    }
+    if (l.kind == 4 || l.kind == 5) {
+        if (wo.z == 0) return f3(0.f, 0.f, 0.f);
+        F3 wh = l.dist.Sample_wh(wo, u0, u1);
+        float dwh = dot3(wo, wh);
+        if (dwh < 0) return f3(0.f, 0.f, 0.f);
+        wi = -wo + (2 * dwh) * wh;                                       // Reflect, reflection.h:48-50
+        if (!same_hemisphere(wo, wi)) return f3(0.f, 0.f, 0.f);
+        pdf = l.dist.Pdf(wo, wh) / (4 * dwh);
+        return lobe_f(l, wo, wi);
+    }
+    return f3(0.f, 0.f, 0.f);
+}
+
+template <int MAT>
+__device__ __forceinline__ bool material_needs_uv(const DevScene &sc, const DevMaterial &m) {
+    bool need = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (m.tex[k] >= 0 && sc.textures[m.tex[k]].kind != 0) need = true;
+    return need;
+}
+
+// Material::ComputeScatteringFunctions, material.cpp:5-82.
+template <int MAT>
+__device__ __forceinline__ void build_lobe(const DevScene &sc, const DevMaterial &m, float u, float v, Lobe &l) {
+    l.kind = 0; l.R = l.eta = l.k = f3(0.f, 0.f, 0.f); l.etaB = 1.f; l.metallic = 0.f; l.dist.ax = l.dist.ay = 1.f;
+    if (MAT == RT_MAT_MATTE) { l.kind = 1; l.R = clamp0(eval_texture(sc.textures[m.tex[0]], u, v)); }
+    else if (MAT == RT_MAT_MIRROR) {
+        F3 R = clamp0(eval_texture(sc.textures[m.tex[0]], u, v));
+        if (!black3(R)) { l.kind = 2; l.R = R; }
+    } else if (MAT == RT_MAT_GLASS) {
+        float eta = eval_texture(sc.textures[m.tex[2]], u, v).x;
+        F3 R = clamp0(eval_texture(sc.textures[m.tex[0]], u, v)), T = clamp0(eval_texture(sc.textures[m.tex[1]], u, v));
+        if (!black3(R) && !black3(T)) { l.kind = 3; l.R = T; l.etaB = eta; }
+    } else if (MAT == RT_MAT_METAL) {
+        float ur = eval_texture(sc.textures[m.tex[2]], u, v).x, vr = eval_texture(sc.textures[m.tex[3]], u, v).x;
+        if (m.remap) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
+        l.kind = 4; l.R = f3(1.f, 1.f, 1.f);
+        l.eta = eval_texture(sc.textures[m.tex[0]], u, v); l.k = eval_texture(sc.textures[m.tex[1]], u, v);
+        l.dist.ax = fmaxf(0.001f, ur); l.dist.ay = fmaxf(0.001f, vr);
+    } else if (MAT == RT_MAT_METALROUGH) {
+        F3 c = clamp0(eval_texture(sc.textures[m.tex[0]], u, v));
+        if (m.tex[1] < 0) { l.kind = 1; l.R = c; }
+        else {
+            F3 tmp = clamp0(eval_texture(sc.textures[m.tex[1]], u, v));
+            float rough = fmaxf(0.05f, tmp.y);
+            l.kind = 5; l.R = c; l.metallic = tmp.z;
+            l.dist.ax = fmaxf(0.001f, rough); l.dist.ay = fmaxf(0.001f, rough);
+        }
+    }
+}
+
+template <int MAT>
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, RenderParams rp, int bounce, PathQueue q, PathQueue qn, HitBuf hb, const uint32_t *cls_list,
+                                                     uint32_t cap, ShadowQueue sq, BounceCounters *counters) {
+    BounceCounters *bc = counters + bounce;
+    const uint32_t n = bc->cls[MAT];
+    const uint32_t *list = cls_list + (size_t)MAT * cap;
+    uint32_t lane = lane_id();
+    while (true) {
+        uint32_t base = wave_fetch(&bc->fetch_cls[MAT]);
+        if (base >= n) break;
+        uint32_t j = base + lane;
+        bool active = j < n;
+        bool has_shadow = false, has_next = false;
+        uint32_t id = 0, nstate = 0;
+        F3 so = f3(0, 0, 0), sd = f3(0, 0, 0), sc3 = f3(0, 0, 0), no = f3(0, 0, 0), nd = f3(0, 0, 0), nT = f3(0, 0, 0);
+        if (active) {
+            uint32_t i = list[j];
+            F3 o = f3(q.ox[i], q.oy[i], q.oz[i]), d = f3(q.dx[i], q.dy[i], q.dz[i]);
+            F3 T = f3(q.tr[i], q.tg[i], q.tb[i]);
+            id = q.id[i];
+            uint32_t state = q.state[i];
+            int depth = state & 0xFFFF;
+            int slot = hb.slot[i];
+            const DevMaterial &m = sc.materials[sc.slot_material[slot]];
+            SurfacePoint sp;
+            surface_point(sc, slot, o, d, hb.t[i], hb.b0[i], hb.b1[i], hb.b2[i], material_needs_uv<MAT>(sc, m), sp);
+            Lobe lobe;
+            build_lobe<MAT>(sc, m, sp.u, sp.v, lobe);
+            uint32_t pixel = id / (uint32_t)rp.spb, sample = (uint32_t)rp.sample0 + id % (uint32_t)rp.spb;
+            uint32_t a0 = pixel, a1 = sample, a2 = (uint32_t)depth, a3 = 0;   // {light pick, uLight.x, uLight.y, roulette}
+            philox4x32(a0, a1, a2, a3, rp.k0, rp.k1);
+            // ---- next-event estimation: UniformSampleOneLight + EstimateDirect, integrator.cpp:53-102,259-264
+            if (lobe.kind != 0 && !lobe_is_specular(lobe.kind) && sc.n_lights > 0) {
+                int nL = sc.n_lights;
+                int ln = min((int)(u32_to_unit(a0) * nL), nL - 1);
+                float selPdf = 1.f / nL;
+                const DevLight &L = sc.lights[ln];
+                float u0 = u32_to_unit(a1), u1 = u32_to_unit(a2);
+                F3 p0 = f3(L.p0[0], L.p0[1], L.p0[2]), p1 = f3(L.p1[0], L.p1[1], L.p1[2]), p2 = f3(L.p2[0], L.p2[1], L.p2[2]);
+                float su0 = sqrtf(u0);
+                float lb0 = 1 - su0, lb1 = u1 * su0;                       // UniformSampleTriangle, sampling.cpp:108-111
+                F3 lp = (lb0 * p0 + lb1 * p1) + (1 - lb0 - lb1) * p2;      // Triangle::Sample, triangle.cpp:229-248
+                F3 lnrm = f3(L.n[0], L.n[1], L.n[2]);
+                if (L.has_n) {
+                    float w2 = 1 - lb0 - lb1;
+                    F3 ns = (lb0 * f3(L.vn[0], L.vn[1], L.vn[2]) + lb1 * f3(L.vn[3], L.vn[4], L.vn[5])) + w2 * f3(L.vn[6], L.vn[7], L.vn[8]);
+                    if (dot3(lnrm, ns) < 0.f) lnrm = -lnrm;
+                }
+                float pdf = 1 / L.area;
+                F3 wi = lp - sp.p;                                          // Shape::Sample(ref,u,pdf), shape.cpp:20-31
+                if (lensq(wi) == 0) pdf = 0;
+                else {
+                    wi = normalize3(wi);
+                    pdf *= lensq(sp.p - lp) / fabsf(dot3(lnrm, -wi));
+                    if (isinf(pdf)) pdf = 0.f;
+                }
+                F3 Li = f3(0.f, 0.f, 0.f);                                  // DiffuseAreaLight::Sample_Li, light.cpp:43-54
+                if (pdf == 0 || lensq(lp - sp.p) == 0) pdf = 0;
+                else {
+                    wi = normalize3(lp - sp.p);
+                    if (L.two_sided || dot3(lnrm, -wi) > 0) Li = f3(L.Le[0], L.Le[1], L.Le[2]);
+                }
+                if (pdf > 0 && !black3(Li)) {
+                    // BSDF::f(wo, wi, ALL & ~SPECULAR) * AbsDot(wi, ns), reflection.cpp:140-152
+                    F3 wol = to_local(sp, sp.wo), wil = to_local(sp, wi);
+                    F3 f = f3(0.f, 0.f, 0.f);
+                    if (wol.z != 0) {
+                        bool reflect = dot3(wi, sp.n) * dot3(sp.wo, sp.n) > 0;
+                        if (reflect) f = lobe_f(lobe, wol, wil);
+                    }
+                    float ad = fabsf(dot3(wi, sp.n));
+                    f = f3(f.x * ad, f.y * ad, f.z * ad);
+                    if (!black3(f)) {
+                        F3 origin = offset_ray_origin(sp.p, sp.n, lp - sp.p);     // Interaction::SpawnRayTo, interaction.h:27-32
+                        F3 target = offset_ray_origin(lp, lnrm, origin - lp);
+                        F3 Ld = cdiv(cdiv(f * Li, pdf), selPdf);
+                        has_shadow = true; so = origin; sd = target - origin; sc3 = T * Ld;
+                    }
+                }
+            }
+            // ---- BSDF sampling, integrator.cpp:265-279 + BSDF::Sample_f reflection.cpp:173-217 (one lobe)
+            if (lobe.kind != 0) {
+                uint32_t b0 = pixel, b1 = sample, b2 = (uint32_t)depth, b3 = 1;   // {bsdf.x, bsdf.y, -, -}
+                philox4x32(b0, b1, b2, b3, rp.k0, rp.k1);
+                float u0 = fminf(u32_to_unit(b0) * 1 - 0, RT_ONE_MINUS_EPS), u1 = u32_to_unit(b1);
+                F3 woW = -d;
+                F3 wol = to_local(sp, woW), wil; float pdf = 0.f;
+                F3 f = f3(0.f, 0.f, 0.f);
+                if (wol.z != 0) {
+                    f = lobe_sample(lobe, wol, u0, u1, wil, pdf);
+                    if (pdf == 0) f = f3(0.f, 0.f, 0.f);
+                    else {
+                        F3 wiW = to_world(sp, wil);
+                        if (!lobe_is_specular(lobe.kind)) {
+                            bool reflect = dot3(wiW, sp.n) * dot3(woW, sp.n) > 0;
+                            f = reflect ? lobe_f(lobe, wol, wil) : f3(0.f, 0.f, 0.f);
+                        }
+                        if (!black3(f) && pdf != 0.f) {
+                            float ad = fabsf(dot3(wiW, sp.n));
+                            F3 beta = cdiv(f3(f.x * ad, f.y * ad, f.z * ad), pdf);
+                            bool alive = true;
+                            if (depth > 3) {
+                                float qq = fmaxf(.05f, 1 - maxcomp3(beta));
+                                if (u32_to_unit(a3) < qq) alive = false;
+                                beta = cdiv(beta, 1 - qq);
+                            }
+                            if (alive) {
+                                has_next = true;
+                                no = offset_ray_origin(sp.p, sp.n, wiW); nd = wiW; nT = T * beta;
+                                nstate = (uint32_t)(depth + 1) | (lobe_is_specular(lobe.kind) ? (1u << 16) : 0u);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        uint32_t spos = wave_append(has_shadow, &bc->n_shadow);
+        if (has_shadow) {
+            sq.id[spos] = id; sq.ox[spos] = so.x; sq.oy[spos] = so.y; sq.oz[spos] = so.z; sq.dx[spos] = sd.x; sq.dy[spos] = sd.y; sq.dz[spos] = sd.z;
+            sq.cr[spos] = sc3.x; sq.cg[spos] = sc3.y; sq.cb[spos] = sc3.z;
+        }
+        uint32_t npos = wave_append(has_next, &counters[bounce + 1].n_queue);
+        if (has_next) {
+            qn.ox[npos] = no.x; qn.oy[npos] = no.y; qn.oz[npos] = no.z; qn.dx[npos] = nd.x; qn.dy[npos] = nd.y; qn.dz[npos] = nd.z;
+            qn.tr[npos] = nT.x; qn.tg[npos] = nT.y; qn.tb[npos] = nT.z; qn.id[npos] = id; qn.state[npos] = nstate;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ shadow --
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, ShadowQueue sq, float4 *lbuf, BounceCounters *counters, int *spill) {
+    __shared__ int s_stack[RT_LDS_STACK * RT_BLOCK];
+    BounceCounters *bc = counters + bounce;
+    const uint32_t n = bc->n_shadow;
+    size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    TravStack st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.sp = 0;
+    uint32_t lane = lane_id();
+    while (true) {
+        uint32_t base = wave_fetch(&bc->fetch_shadow);
+        if (base >= n) break;
+        uint32_t i = base + lane;
+        if (i < n) {
+            F3 o = f3(sq.ox[i], sq.oy[i], sq.oz[i]), d = f3(sq.dx[i], sq.dy[i], sq.dz[i]);
+            HitRec h; uint32_t c0 = 0, c1 = 0;
+            bool occluded = traverse<true, false>(sc, o, d, 1.f - 0.0001f, st, h, c0, c1);   // tMax = 1 - ShadowEpsilon
+            if (!occluded) {
+                uint32_t id = sq.id[i];
+                float4 L = lbuf[id];
+                L.x += sq.cr[i]; L.y += sq.cg[i]; L.z += sq.cb[i];
+                lbuf[id] = L;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------- accumulate --
+__global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const float4 *lbuf, int spb, uint32_t npix, float *sum_rgb) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        float r = sum_rgb[3 * (size_t)p], g = sum_rgb[3 * (size_t)p + 1], b = sum_rgb[3 * (size_t)p + 2];
+        for (int s = 0; s < spb; ++s) { float4 L = lbuf[(size_t)p * spb + s]; r += L.x; g += L.y; b += L.z; }
+        sum_rgb[3 * (size_t)p] = r; sum_rgb[3 * (size_t)p + 1] = g; sum_rgb[3 * (size_t)p + 2] = b;
+    }
+}
+
+// ==================================================================== host ==
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    int n_cu = 256;
+};
+static std::string g_init_error;
+static void set_error(rt_ctx *c, const std::string &s) { if (c) c->error = s; else g_init_error = s; }
+
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t b) { if (p) { (void)hipFree(p); p = nullptr; } bytes = b; return b ? hipMalloc(&p, b) : hipSuccess; }
+    hipError_t ensure(size_t b) { if (b <= bytes && p) return hipSuccess; return alloc(b); }
+};
+
+struct rt_scene {
+    rt_ctx *ctx = nullptr;
+    DevScene dev;
+    std::vector<rt_bvh_node> nodes; std::vector<int32_t> order;
+    int n_prims = 0;
+    bool classes[RT_NUM_CLASSES] = {false, false, false, false, false, false};
+    DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_spill;
+    std::vector<DevBuf *> d_texels;
+    // render workspace
+    DevBuf d_q[2], d_hits, d_cls, d_shadow, d_lbuf, d_counters, d_sum, d_trace_io, d_work;
+    size_t ws_cap = 0, sum_pixels = 0;
+    ~rt_scene() { for (DevBuf *b : d_texels) delete b; }
+};
+
+static rt_ctx *ctx_of(rt_ctx *c) { return c; }
+static rt_ctx *ctx_of(rt_scene *s) { return s ? s->ctx : nullptr; }
+
+static int persistent_grid(rt_ctx *c) { return c->n_cu * 8; }
+
+namespace {
+// Host-side copies of the reference's float helpers used while precomputing per-triangle frames
+// (triangle.cpp:121-146, reflection.h:139-141).  Built with -ffp-contract=off like the rest of the host code.
+struct H3 { float x, y, z; };
+inline H3 h3(float x, float y, float z) { H3 r = {x, y, z}; return r; }
+inline H3 hsub(H3 a, H3 b) { return h3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline H3 hscale(H3 v, float s) { return h3(s * v.x, s * v.y, s * v.z); }
+inline H3 hdivv(H3 v, float f) { float inv = 1.f / f; return h3(v.x * inv, v.y * inv, v.z * inv); }
+inline float hlen2(H3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
+inline H3 hnorm(H3 v) { return hdivv(v, std::sqrt(hlen2(v))); }
+inline H3 hcross(H3 a, H3 b) {
+    double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
+    return h3((float)((ay * bz) - (az * by)), (float)((az * bx) - (ax * bz)), (float)((ax * by) - (ay * bx)));
+}
+inline void hcoordsys(H3 v1, H3 *v2, H3 *v3) {
+    if (std::abs(v1.x) > std::abs(v1.y)) *v2 = hdivv(h3(-v1.z, 0, v1.x), std::sqrt(v1.x * v1.x + v1.z * v1.z));
+    else *v2 = hdivv(h3(0, v1.z, -v1.y), std::sqrt(v1.y * v1.y + v1.z * v1.z));
+    *v3 = hcross(v1, *v2);
+}
+// Returns false when Triangle::Intersect would reject every hit on this triangle.
+bool triangle_frame(const float *P, const float *UV, H3 *n, H3 *ss, H3 *ts) {
+    H3 p0 = h3(P[0], P[1], P[2]), p1 = h3(P[3], P[4], P[5]), p2 = h3(P[6], P[7], P[8]);
+    float duv02x = UV[0] - UV[4], duv02y = UV[1] - UV[5], duv12x = UV[2] - UV[4], duv12y = UV[3] - UV[5];
+    H3 dp02 = hsub(p0, p2), dp12 = hsub(p1, p2);
+    float determinant = duv02x * duv12y - duv02y * duv12x;
+    bool degenerateUV = std::abs(determinant) < 1e-8;
+    H3 dpdu = h3(0, 0, 0), dpdv = h3(0, 0, 0);
+    if (!degenerateUV) {
+        float invdet = 1 / determinant;
+        H3 a = hscale(dp02, duv12y), b = hscale(dp12, duv02y);
+        dpdu = hscale(hsub(a, b), invdet);
+        H3 c = hscale(dp02, -duv12x), e = hscale(dp12, duv02x);
+        dpdv = hscale(h3(c.x + e.x, c.y + e.y, c.z + e.z), invdet);
+    }
+    bool ok = true;
+    if (degenerateUV || hlen2(hcross(dpdu, dpdv)) == 0) {
+        H3 ng = hcross(hsub(p2, p0), hsub(p1, p0));
+        if (hlen2(ng) == 0) ok = false;
+        else hcoordsys(hnorm(ng), &dpdu, &dpdv);
+    }
+    *n = hnorm(hcross(dp02, dp12));
+    *ss = hnorm(dpdu);
+    *ts = hcross(*n, *ss);
+    return ok;
+}
+bool is_affine(const float *m) { return m[12] == 0.f && m[13] == 0.f && m[14] == 0.f && m[15] == 1.f; }
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(rt_ctx *ctx) { return ctx ? ctx->error.c_str() : g_init_error.c_str(); }
+
+int rt_init(int device, rt_ctx **out) {
+    if (!out) return -1;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_init_error = "no HIP device available (this library has no CPU path)"; return -3; }
+    if (device < 0 || device >= n) { g_init_error = "device index out of range"; return -1; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { g_init_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return -2; }
+    rt_ctx *c = new rt_ctx; c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreate(&c->stream)) != hipSuccess) { g_init_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return -2; }
+    *out = c;
+    return 0;
+}
+void rt_shutdown(rt_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
+    if (!this_ || !d || !out) return -1;
+    rt_ctx *ctx = this_;
+    HIP_OK(hipSetDevice(ctx->device));
+    if (d->n_prims <= 0) { set_error(ctx, "rt_scene_create: empty scene"); return -1; }
+    std::unique_ptr<rt_scene> sc(new rt_scene);
+    sc->ctx = ctx; sc->n_prims = d->n_prims;
+    if (d->bvh_nodes) {
+        if (!d->prim_order || d->n_nodes <= 0) { set_error(ctx, "rt_scene_create: bvh_nodes given without prim_order"); return -1; }
+        sc->nodes.assign(d->bvh_nodes, d->bvh_nodes + d->n_nodes); sc->order.assign(d->prim_order, d->prim_order + d->n_prims);
+    } else {
+        std::vector<float> pb(6 * (size_t)d->n_prims);
+        rt_prim_bounds(d, pb.data());
+        sc->nodes.resize(2 * (size_t)d->n_prims); sc->order.resize(d->n_prims);
+        int32_t nn = 0;
+        if (rt_bvh_build(d->n_prims, pb.data(), sc->nodes.data(), &nn, sc->order.data()) != 0) { set_error(ctx, "rt_bvh_build failed"); return -1; }
+        sc->nodes.resize(nn);
+    }
+    // validate the tree before any kernel walks it
+    int nn = (int)sc->nodes.size();
+    for (int i = 0; i < nn; ++i) {
+        const rt_bvh_node &nd = sc->nodes[i];
+        if (nd.nprim > 0) { if (nd.offset < 0 || nd.offset + nd.nprim > d->n_prims) { set_error(ctx, "rt_scene_create: leaf range out of bounds"); return -1; } }
+        else if (nd.offset <= i || nd.offset >= nn || i + 1 >= nn || nd.axis > 2) { set_error(ctx, "rt_scene_create: interior node links out of bounds"); return -1; }
+    }
+    for (int i = 0; i < d->n_prims; ++i) {
+        int p = sc->order[i];
+        if (p < 0 || p >= d->n_prims) { set_error(ctx, "rt_scene_create: prim_order out of range"); return -1; }
+        int g = d->prim_geom[p], k = d->prim_kind[p], m = d->prim_material[p], l = d->prim_light[p];
+        if ((k == RT_PRIM_TRIANGLE && (g < 0 || g >= d->n_tris)) || (k == RT_PRIM_SPHERE && (g < 0 || g >= d->n_spheres)) || (k != RT_PRIM_TRIANGLE && k != RT_PRIM_SPHERE) ||
+            m < 0 || m >= d->n_materials || l >= d->n_lights) { set_error(ctx, "rt_scene_create: primitive references out of range"); return -1; }
+    }
+    for (int i = 0; i < d->n_materials; ++i) {
+        const rt_material &m = d->materials[i];
+        if (m.kind < 0 || m.kind >= RT_NUM_CLASSES) { set_error(ctx, "rt_scene_create: unknown material kind"); return -1; }
+        if (m.kind == RT_MAT_PLASTIC) { set_error(ctx, "rt_scene_create: PlasticMaterial (two-lobe BSDF) is not implemented on the device"); return -1; }
+        int need = m.kind == RT_MAT_MATTE || m.kind == RT_MAT_MIRROR ? 1 : m.kind == RT_MAT_GLASS ? 3 : m.kind == RT_MAT_METAL ? 4 : 1;
+        for (int k = 0; k < 4; ++k) {
+            if (m.tex[k] >= d->n_textures || (k < need && m.tex[k] < 0)) { set_error(ctx, "rt_scene_create: material texture slot out of range"); return -1; }
+        }
+        sc->classes[m.kind] = true;
+    }
+    // slots
+    size_t ns = (size_t)d->n_prims;
+    std::vector<float> slots(12 * ns), frames(12 * ns, 0.f), uv(6 * ns, 0.f);
+    std::vector<int> smat(ns), slight(ns);
+    std::vector<float> spheres(32 * (size_t)std::max(1, d->n_spheres), 0.f);
+    for (int s = 0; s < d->n_spheres; ++s) {
+        const rt_sphere &S = d->spheres[s];
+        if (!is_affine(S.o2w) || !is_affine(S.w2o)) { set_error(ctx, "rt_scene_create: sphere transforms must be affine"); return -1; }
+        float *r = &spheres[32 * (size_t)s];
+        r[0] = S.radius; memcpy(r + 4, S.w2o, 48); memcpy(r + 16, S.o2w, 48);
+    }
+    for (size_t s = 0; s < ns; ++s) {
+        int p = sc->order[s]; int g = d->prim_geom[p];
+        float *r = &slots[12 * s]; uint32_t flags = 0; int32_t geom = 0;
+        if (d->prim_kind[p] == RT_PRIM_TRIANGLE) {
+            const float *P = d->tri_p + 9 * (size_t)g, *UV = d->tri_uv + 6 * (size_t)g;
+            memcpy(r, P, 36); memcpy(&uv[6 * s], UV, 24);
+            H3 n, ss, ts;
+            if (!triangle_frame(P, UV, &n, &ss, &ts)) flags |= RT_SLOT_REJECT_CLOSEST;
+            float *f = &frames[12 * s];
+            f[0] = n.x; f[1] = n.y; f[2] = n.z; f[4] = ss.x; f[5] = ss.y; f[6] = ss.z; f[8] = ts.x; f[9] = ts.y; f[10] = ts.z;
+        } else { flags |= RT_SLOT_SPHERE; geom = g; }
+        memcpy(r + 9, &flags, 4); memcpy(r + 10, &p, 4); memcpy(r + 11, &geom, 4);
+        smat[s] = d->prim_material[p]; slight[s] = d->prim_light[p];
+    }
+    std::vector<DevLight> lights((size_t)std::max(1, d->n_lights));
+    for (int i = 0; i < d->n_lights; ++i) {
+        const rt_light &L = d->lights[i]; DevLight &D = lights[i]; memset(&D, 0, sizeof(D));
+        if (L.prim < 0 || L.prim >= d->n_prims || d->prim_kind[L.prim] != RT_PRIM_TRIANGLE) { set_error(ctx, "rt_scene_create: area lights must be triangles"); return -1; }
+        size_t g = (size_t)d->prim_geom[L.prim];
+        const float *P = d->tri_p + 9 * g;
+        memcpy(D.p0, P, 12); memcpy(D.p1, P + 3, 12); memcpy(D.p2, P + 6, 12);
+        H3 p0 = h3(P[0], P[1], P[2]), p1 = h3(P[3], P[4], P[5]), p2 = h3(P[6], P[7], P[8]);
+        H3 c = hcross(hsub(p1, p0), hsub(p2, p0));
+        H3 n = hnorm(c);
+        D.n[0] = n.x; D.n[1] = n.y; D.n[2] = n.z;
+        D.area = (float)(0.5 * std::sqrt(hlen2(c)));
+        if (!(D.area > 0.f)) { set_error(ctx, "rt_scene_create: degenerate light triangle"); return -1; }
+        if (d->tri_n && d->tri_has_n && d->tri_has_n[g]) { D.has_n = 1; memcpy(D.vn, d->tri_n + 9 * g, 36); }
+        D.Le[0] = L.Le[0]; D.Le[1] = L.Le[1]; D.Le[2] = L.Le[2]; D.two_sided = L.two_sided;
+    }
+    std::vector<DevTexture> tex((size_t)std::max(1, d->n_textures));
+    for (int i = 0; i < d->n_textures; ++i) {
+        const rt_texture &T = d->textures[i]; DevTexture &D = tex[i]; memset(&D, 0, sizeof(D));
+        D.kind = T.kind; D.width = T.width; D.height = T.height; memcpy(D.value, T.value, 12); D.su = T.su; D.sv = T.sv; D.du = T.du; D.dv = T.dv;
+        if (T.kind == RT_TEX_IMAGE) {
+            if (T.width <= 0 || T.height <= 0 || !T.texels) { set_error(ctx, "rt_scene_create: image texture without texels"); return -1; }
+            size_t bytes = (size_t)T.width * T.height * 3 * sizeof(float);
+            DevBuf *b = new DevBuf; sc->d_texels.push_back(b);
+            HIP_OK(b->alloc(bytes));
+            HIP_OK(hipMemcpy(b->p, T.texels, bytes, hipMemcpyHostToDevice));
+            D.texels = (const float *)b->p;
+        } else if (T.kind != RT_TEX_CONST) { set_error(ctx, "rt_scene_create: unknown texture kind"); return -1; }
+    }
+    std::vector<DevMaterial> mats((size_t)d->n_materials);
+    for (int i = 0; i < d->n_materials; ++i) { mats[i].kind = d->materials[i].kind; memcpy(mats[i].tex, d->materials[i].tex, 16); mats[i].remap = d->materials[i].remap_roughness; }
+
+    auto up = [&](DevBuf &b, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = b.alloc(bytes); if (e != hipSuccess) return e;
+        return hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+    };
+    HIP_OK(up(sc->d_nodes, sc->nodes.data(), sc->nodes.size() * sizeof(rt_bvh_node)));
+    HIP_OK(up(sc->d_slots, slots.data(), slots.size() * 4));
+    HIP_OK(up(sc->d_frames, frames.data(), frames.size() * 4));
+    HIP_OK(up(sc->d_uv, uv.data(), uv.size() * 4));
+    HIP_OK(up(sc->d_spheres, spheres.data(), spheres.size() * 4));
+    HIP_OK(up(sc->d_slot_mat, smat.data(), smat.size() * 4));
+    HIP_OK(up(sc->d_slot_light, slight.data(), slight.size() * 4));
+    HIP_OK(up(sc->d_mats, mats.data(), mats.size() * sizeof(DevMaterial)));
+    HIP_OK(up(sc->d_tex, tex.data(), tex.size() * sizeof(DevTexture)));
+    HIP_OK(up(sc->d_lights, lights.data(), lights.size() * sizeof(DevLight)));
+    size_t spill_ints = (size_t)persistent_grid(ctx) * RT_BLOCK * (RT_MAX_STACK - RT_LDS_STACK);
+    HIP_OK(sc->d_spill.alloc(spill_ints * 4));
+    DevScene &D = sc->dev;
+    D.nodes = (const float4 *)sc->d_nodes.p; D.slots = (const float4 *)sc->d_slots.p; D.frames = (const float4 *)sc->d_frames.p;
+    D.slot_uv = (const float *)sc->d_uv.p; D.spheres = (const float *)sc->d_spheres.p; D.slot_material = (const int *)sc->d_slot_mat.p;
+    D.slot_light = (const int *)sc->d_slot_light.p; D.materials = (const DevMaterial *)sc->d_mats.p; D.textures = (const DevTexture *)sc->d_tex.p;
+    D.lights = (const DevLight *)sc->d_lights.p; D.n_nodes = nn; D.n_slots = d->n_prims; D.n_lights = d->n_lights; D.pad = 0;
+    *out = sc.release();
+    return 0;
+}
+
+void rt_scene_destroy(rt_scene *scene) {
+    if (!scene) return;
+    (void)hipSetDevice(scene->ctx->device);
+    (void)hipStreamSynchronize(scene->ctx->stream);
+    delete scene;
+}
+
+int rt_scene_get_bvh(rt_scene *this_, rt_bvh_node *nodes_out, int32_t *n_nodes_out, int32_t *order_out) {
+    if (!this_ || !n_nodes_out) return -1;
+    *n_nodes_out = (int32_t)this_->nodes.size();
+    if (nodes_out) memcpy(nodes_out, this_->nodes.data(), this_->nodes.size() * sizeof(rt_bvh_node));
+    if (order_out) memcpy(order_out, this_->order.data(), this_->order.size() * sizeof(int32_t));
+    return 0;
+}
+
+static int trace_host(rt_scene *this_, bool any, size_t n, const float *o, const float *d, const float *tmax, int32_t *out_prim, float *out_t, float *out_b,
+                      uint8_t *out_hit) {
+    rt_ctx *ctx = this_->ctx;
+    if (n == 0) return 0;
+    HIP_OK(hipSetDevice(ctx->device));
+    std::vector<float> rays(7 * n);
+    for (size_t i = 0; i < n; ++i) { memcpy(&rays[7 * i], o + 3 * i, 12); memcpy(&rays[7 * i + 3], d + 3 * i, 12); rays[7 * i + 6] = tmax[i]; }
+    size_t in_bytes = 7 * n * 4, out_bytes = any ? n : 16 * n;
+    HIP_OK(this_->d_trace_io.ensure(in_bytes + out_bytes + 256));
+    char *base = (char *)this_->d_trace_io.p;
+    HIP_OK(hipMemcpyAsync(base, rays.data(), in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    char *outp = base + ((in_bytes + 255) & ~(size_t)255);
+    int grid = (int)std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)persistent_grid(ctx));
+    if (any)
+        hipLaunchKernelGGL((k_trace_batch<true, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, (const float *)base, 1, nullptr, nullptr, nullptr,
+                           nullptr, (uint8_t *)outp, (int *)this_->d_spill.p, nullptr);
+    else
+        hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, (const float *)base, 1, (int *)outp,
+                           (float *)outp + n, (float *)outp + 2 * n, (float *)outp + 3 * n, nullptr, (int *)this_->d_spill.p, nullptr);
+    HIP_OK(hipGetLastError());
+    if (any) HIP_OK(hipMemcpyAsync(out_hit, outp, n, hipMemcpyDeviceToHost, ctx->stream));
+    else {
+        HIP_OK(hipMemcpyAsync(out_prim, outp, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_OK(hipMemcpyAsync(out_t, outp + 4 * n, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    std::vector<float> b12;
+    if (!any && out_b) { b12.resize(2 * n); HIP_OK(hipMemcpyAsync(b12.data(), outp + 8 * n, 8 * n, hipMemcpyDeviceToHost, ctx->stream)); }
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    if (!any && out_b) for (size_t i = 0; i < n; ++i) { out_b[2 * i] = b12[i]; out_b[2 * i + 1] = b12[n + i]; }
+    return 0;
+}
+
+int rt_trace_closest(rt_scene *scene, size_t n, const float *o, const float *d, const float *tmax, int32_t *out_prim, float *out_t, float *out_b) {
+    if (!scene || (n && (!o || !d || !tmax || !out_prim || !out_t))) return -1;
+    return trace_host(scene, false, n, o, d, tmax, out_prim, out_t, out_b, nullptr);
+}
+int rt_trace_any(rt_scene *scene, size_t n, const float *o, const float *d, const float *tmax, uint8_t *out_hit) {
+    if (!scene || (n && (!o || !d || !tmax || !out_hit))) return -1;
+    return trace_host(scene, true, n, o, d, tmax, nullptr, nullptr, nullptr, out_hit);
+}
+
+int rt_trace_closest_device(rt_scene *this_, size_t n, const void *rays, void *hits, int repeats, int count_work, rt_trace_stats *stats) {
+    if (!this_ || !rays || !hits || n == 0) return -1;
+    rt_ctx *ctx = this_->ctx;
+    HIP_OK(hipSetDevice(ctx->device));
+    if (repeats < 1) repeats = 1;
+    int grid = (int)std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)persistent_grid(ctx));
+    int *prim = (int *)hits; float *t = (float *)hits + n, *b1 = (float *)hits + 2 * n, *b2 = (float *)hits + 3 * n;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (count_work) {
+        HIP_OK(this_->d_work.ensure(16));
+        HIP_OK(hipMemsetAsync(this_->d_work.p, 0, 16, ctx->stream));
+        hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, (const float *)rays, 0, prim, t, b1, b2, nullptr,
+                           (int *)this_->d_spill.p, (unsigned long long *)this_->d_work.p);
+        HIP_OK(hipGetLastError());
+        unsigned long long w[2];
+        HIP_OK(hipMemcpyAsync(w, this_->d_work.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+        if (stats) { stats->nodes_visited = w[0]; stats->prims_tested = w[1]; }
+    }
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < repeats; ++r)
+        hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, (const float *)rays, 0, prim, t, b1, b2, nullptr,
+                           (int *)this_->d_spill.p, nullptr);
+    HIP_OK(hipEventRecord(e1, ctx->stream));
+    HIP_OK(hipEventSynchronize(e1));
+    HIP_OK(hipGetLastError());
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (stats) stats->seconds = (double)ms * 1e-3 / repeats;
+    return 0;
+}
+
+static void bind_queue(PathQueue &q, void *base, size_t cap) {
+    float *f = (float *)base;
+    q.ox = f; q.oy = f + cap; q.oz = f + 2 * cap; q.dx = f + 3 * cap; q.dy = f + 4 * cap; q.dz = f + 5 * cap;
+    q.tr = f + 6 * cap; q.tg = f + 7 * cap; q.tb = f + 8 * cap; q.id = (uint32_t *)(f + 9 * cap); q.state = (uint32_t *)(f + 10 * cap);
+}
+
+extern "C++" {
+template <int MAT>
+static void launch_shade(rt_scene *s, int grid, const RenderParams &rp, int bounce, const PathQueue &q, const PathQueue &qn, const HitBuf &hb, uint32_t cap,
+                         const ShadowQueue &sq) {
+    hipLaunchKernelGGL((k_shade<MAT>), dim3(grid), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p, cap, sq,
+                       (BounceCounters *)s->d_counters.p);
+}
+}  // extern "C++"
+
+int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts *o, void **out_device_sum, rt_render_stats *stats) {
+    if (!this_ || !cam || !o || !out_device_sum) return -1;
+    rt_ctx *ctx = this_->ctx;
+    HIP_OK(hipSetDevice(ctx->device));
+    int W = cam->width, H = cam->height;
+    if (W <= 0 || H <= 0 || o->strata_x <= 0 || o->strata_y <= 0 || o->sample_begin < 0 || o->sample_end < o->sample_begin || o->max_depth < 0 || o->max_depth > 65534) {
+        set_error(ctx, "rt_render: invalid camera or options"); return -1;
+    }
+    size_t npix = (size_t)W * H;
+    if (npix > (1u << 30)) { set_error(ctx, "rt_render: image too large"); return -1; }
+    int S = o->sample_end - o->sample_begin;
+    size_t pool = o->pool_paths > 0 ? (size_t)o->pool_paths : ((size_t)16 << 20);
+    int spb = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(S, 1), pool / npix));
+    size_t cap = npix * (size_t)spb;
+    if (cap >= (1ull << 31)) { set_error(ctx, "rt_render: pass too large"); return -1; }
+    if (cap > this_->ws_cap) {
+        HIP_OK(this_->d_q[0].alloc(11 * cap * 4)); HIP_OK(this_->d_q[1].alloc(11 * cap * 4));
+        HIP_OK(this_->d_hits.alloc(5 * cap * 4)); HIP_OK(this_->d_cls.alloc((size_t)RT_NUM_CLASSES * cap * 4));
+        HIP_OK(this_->d_shadow.alloc(10 * cap * 4)); HIP_OK(this_->d_lbuf.alloc(cap * 16));
+        this_->ws_cap = cap;
+    }
+    size_t n_bounce = (size_t)o->max_depth + 2;
+    HIP_OK(this_->d_counters.ensure(n_bounce * sizeof(BounceCounters)));
+    bool fresh = this_->sum_pixels != npix || !(o->flags & RT_RENDER_ACCUMULATE);
+    if (this_->sum_pixels != npix) { HIP_OK(this_->d_sum.alloc(npix * 3 * 4)); this_->sum_pixels = npix; }
+    if (fresh) HIP_OK(hipMemsetAsync(this_->d_sum.p, 0, npix * 3 * 4, ctx->stream));
+
+    size_t wcap = this_->ws_cap;
+    PathQueue q[2]; bind_queue(q[0], this_->d_q[0].p, wcap); bind_queue(q[1], this_->d_q[1].p, wcap);
+    HitBuf hb; { float *f = (float *)this_->d_hits.p; hb.slot = (int *)f; hb.t = f + wcap; hb.b0 = f + 2 * wcap; hb.b1 = f + 3 * wcap; hb.b2 = f + 4 * wcap; }
+    ShadowQueue sq; { float *f = (float *)this_->d_shadow.p; sq.id = (uint32_t *)f; sq.ox = f + wcap; sq.oy = f + 2 * wcap; sq.oz = f + 3 * wcap; sq.dx = f + 4 * wcap;
+                      sq.dy = f + 5 * wcap; sq.dz = f + 6 * wcap; sq.cr = f + 7 * wcap; sq.cg = f + 8 * wcap; sq.cb = f + 9 * wcap; }
+    BounceCounters *counters = (BounceCounters *)this_->d_counters.p;
+    float4 *lbuf = (float4 *)this_->d_lbuf.p;
+    int grid = persistent_grid(ctx);
+
+    RenderParams rp; memset(&rp, 0, sizeof(rp));
+    memcpy(rp.r2c, cam->raster_to_camera, 64); memcpy(rp.c2w, cam->camera_to_world, 64);
+    rp.width = W; rp.height = H; rp.strata_x = o->strata_x; rp.strata_y = o->strata_y; rp.max_depth = o->max_depth; rp.k0 = o->seed_lo; rp.k1 = o->seed_hi;
+
+    rt_render_stats st; memset(&st, 0, sizeof(st));
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, ctx->stream));
+    std::vector<BounceCounters> hc(n_bounce);
+    for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
+        int cur = std::min(spb, o->sample_end - s0);
+        rp.spb = cur; rp.sample0 = s0; rp.n_paths = (uint32_t)(npix * (size_t)cur);
+        HIP_OK(hipMemsetAsync(counters, 0, n_bounce * sizeof(BounceCounters), ctx->stream));
+        int rg = (int)std::min<size_t>(((size_t)rp.n_paths + RT_BLOCK - 1) / RT_BLOCK, (size_t)grid * 4);
+        hipLaunchKernelGGL(k_raygen, dim3(rg), dim3(RT_BLOCK), 0, ctx->stream, rp, q[0], lbuf, counters);
+        int cq = 0;
+        for (int b = 0; b <= o->max_depth; ++b) {
+            hipLaunchKernelGGL(k_extend, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p, (uint32_t)wcap, lbuf,
+                               counters, (int *)this_->d_spill.p);
+            if (b < o->max_depth) {
+                if (this_->classes[RT_MAT_MATTE]) launch_shade<RT_MAT_MATTE>(this_, grid, rp, b, q[cq], q[cq ^ 1], hb, (uint32_t)wcap, sq);
+                if (this_->classes[RT_MAT_MIRROR]) launch_shade<RT_MAT_MIRROR>(this_, grid, rp, b, q[cq], q[cq ^ 1], hb, (uint32_t)wcap, sq);
+                if (this_->classes[RT_MAT_GLASS]) launch_shade<RT_MAT_GLASS>(this_, grid, rp, b, q[cq], q[cq ^ 1], hb, (uint32_t)wcap, sq);
+                if (this_->classes[RT_MAT_METAL]) launch_shade<RT_MAT_METAL>(this_, grid, rp, b, q[cq], q[cq ^ 1], hb, (uint32_t)wcap, sq);
+                if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, grid, rp, b, q[cq], q[cq ^ 1], hb, (uint32_t)wcap, sq);
+                if (this_->dev.n_lights > 0)
+                    hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, lbuf, counters, (int *)this_->d_spill.p);
+            }
+            cq ^= 1;
+        }
+        int ag = (int)std::min<size_t>((npix + RT_BLOCK - 1) / RT_BLOCK, (size_t)grid * 4);
+        hipLaunchKernelGGL(k_accumulate, dim3(ag), dim3(RT_BLOCK), 0, ctx->stream, (const float4 *)lbuf, cur, (uint32_t)npix, (float *)this_->d_sum.p);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpyAsync(hc.data(), counters, n_bounce * sizeof(BounceCounters), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+        st.samples += rp.n_paths;
+        for (size_t b = 0; b < n_bounce; ++b) { st.rays_closest += hc[b].n_queue; st.rays_shadow += hc[b].n_shadow; if (hc[b].n_queue) st.iterations++; }
+    }
+    HIP_OK(hipEventRecord(e1, ctx->stream));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    st.seconds_total = (double)ms * 1e-3;
+    if (stats) *stats = st;
+    *out_device_sum = this_->d_sum.p;
+    return 0;
+}
+
+int rt_render(rt_scene *this_, const rt_camera *cam, const rt_render_opts *opts, float *out_sum_rgb, rt_render_stats *stats) {
+    if (!this_ || !out_sum_rgb) return -1;
+    void *dsum = nullptr;
+    int rc = rt_render_device(this_, cam, opts, &dsum, stats);
+    if (rc != 0) return rc;
+    rt_ctx *ctx = this_->ctx;
+    HIP_OK(hipMemcpy(out_sum_rgb, dsum, (size_t)cam->width * cam->height * 3 * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+// scenes.cpp — the scenes of the reference's entry file, written against the host surface
+// of rt_host.h, plus a C API so tests and benchmarks can obtain flattened scenes.
+//
+// Scene contents follow the reference's scene functions (RayTracing/RayTracing.cpp):
+//   "cornell"   Cornellbox()      :46-192
+//   "sphere1"   sphere1()         :344-408
+//   "helmet"    DamagedHelmet()   :218-316
+//   "spheres2"  sphere1() plus a GlassMaterial sphere and an earth-textured sphere
+//               (the Lambertian / metal / dielectric + earthmap configuration)
+//   "soup"      N random triangles in a 100^3 box (BVH traversal stress; no reference counterpart)
+#include "rt_host.h"
+
+#include <stdexcept>
+
+namespace {
+
+struct BuiltScene {
+    std::shared_ptr<Scene> scene;        // object graph (empty for "soup")
+    std::unique_ptr<FlatScene> flat;
+    Transform lookat;
+    Float fov = 40.0f, nearPlane = 0.01f;
+    std::vector<std::unique_ptr<Transform>> xforms;   // shapes keep raw Transform pointers
+    std::vector<std::unique_ptr<ModelLoad>> loaders;
+    const Transform *Keep(const Transform &t) { xforms.emplace_back(new Transform(t)); return xforms.back().get(); }
+};
+
+std::string g_error;
+
+std::shared_ptr<Texture<Spectrum>> Const(const Spectrum &s) { return make_shared<ConstantTexture<Spectrum>>(s); }
+std::shared_ptr<Texture<Float>> ConstF(Float v) { return make_shared<ConstantTexture<Float>>(v); }
+std::shared_ptr<Material> Matte(const Spectrum &s) { return make_shared<MatteMaterial>(Const(s), ConstF(0.0f)); }
+
+// The reference writes its boxes as 12 explicit triangles.  Corner code per vertex:
+// x,z in {0,1} times `side`; y in {0, T (yTop), S (ySide)}.  Faces in the reference's order:
+// y=0, y=yTop, z=0, x=0, x=side, z=side (RayTracing.cpp:99-109,136-149,163-176).
+enum { Y0, YT, YS };
+const unsigned char kBoxPattern[12][3][3] = {
+    {{0, Y0, 1}, {1, Y0, 1}, {0, Y0, 0}}, {{1, Y0, 1}, {1, Y0, 0}, {0, Y0, 0}},
+    {{0, YT, 1}, {0, YT, 0}, {1, YT, 1}}, {{1, YT, 1}, {0, YT, 0}, {1, YT, 0}},
+    {{0, Y0, 0}, {1, Y0, 0}, {1, YS, 0}}, {{0, Y0, 0}, {1, YS, 0}, {0, YS, 0}},
+    {{0, Y0, 0}, {0, YS, 1}, {0, Y0, 1}}, {{0, Y0, 0}, {0, YS, 0}, {0, YS, 1}},
+    {{1, Y0, 0}, {1, YS, 1}, {1, Y0, 1}}, {{1, Y0, 0}, {1, YS, 0}, {1, YS, 1}},
+    {{0, Y0, 1}, {1, Y0, 1}, {1, YS, 1}}, {{0, Y0, 1}, {1, YS, 1}, {0, YS, 1}},
+};
+std::vector<std::shared_ptr<Shape>> BoxTriangles(BuiltScene &bs, const Transform &o2w, int nTris, Float side, Float yTop, Float ySide) {
+    std::vector<Point3f> P; std::vector<int> idx;
+    for (int t = 0; t < nTris; ++t)
+        for (int k = 0; k < 3; ++k) {
+            const unsigned char *c = kBoxPattern[t][k];
+            Float y = c[1] == Y0 ? 0.f : (c[1] == YT ? yTop : ySide);
+            P.push_back(Point3f(c[0] ? side : 0.f, y, c[2] ? side : 0.f));
+            idx.push_back((int)idx.size());
+        }
+    const Transform *po = bs.Keep(o2w), *pi = bs.Keep(Inverse(o2w));
+    return CreateTriangleMesh(po, pi, false, nTris, idx.data(), (int)P.size(), P.data(), nullptr, nullptr, nullptr, nullptr);
+}
+// The 1x1 ceiling light: two triangles at height y (RayTracing.cpp:73-90, 247-264).
+void AddCeilingLight(BuiltScene &bs, std::vector<std::shared_ptr<Primitive>> &prims, std::vector<std::shared_ptr<Light>> &lights,
+                     const std::shared_ptr<Material> &mat, Float emit) {
+    float length_Floor = 5;
+    const float y = length_Floor - 0.01;
+    float len = 0.5;
+    Point3f P[6] = {Point3f(-len, y, len), Point3f(-len, y, -len), Point3f(len, y, len), Point3f(len, y, len), Point3f(-len, y, -len), Point3f(len, y, -len)};
+    int idx[6] = {0, 1, 2, 3, 4, 5};
+    Transform o2w = Translate(Vector3f(2.5f, 0.0f, 2.5f)) * Transform();
+    const Transform *po = bs.Keep(o2w), *pi = bs.Keep(Inverse(o2w));
+    auto tris = CreateTriangleMesh(po, pi, false, 2, idx, 6, P, nullptr, nullptr, nullptr, nullptr);
+    for (int i = 0; i < 2; ++i) {
+        std::shared_ptr<AreaLight> area = make_shared<DiffuseAreaLight>(*po, Spectrum(emit), 1, tris[i], false);
+        lights.push_back(area);
+        prims.push_back(make_shared<GeometricPrimitive>(tris[i], mat, area));
+    }
+}
+
+void BuildCornell(BuiltScene &bs) {
+    std::vector<std::shared_ptr<Primitive>> prims; std::vector<std::shared_ptr<Light>> lights;
+    AddCeilingLight(bs, prims, lights, Matte(Spectrum(1.0f, 1.0f, 1.0f)), 20.f);
+    std::shared_ptr<Material> mirror = make_shared<MirrorMaterial>(Const(Spectrum(1.f)));
+    std::shared_ptr<Material> mgreen = Matte(Spectrum(.12f, .45f, .15f)), mred = Matte(Spectrum(.65f, .05f, .05f)), mwhite = Matte(Spectrum(.73f, .73f, .73f));
+    Float L = 5;
+    auto room = BoxTriangles(bs, Transform(), 10, L, L, L);
+    for (int i = 0; i < 10; ++i) prims.push_back(make_shared<GeometricPrimitive>(room[i], i < 6 ? mwhite : (i < 8 ? mred : mgreen), nullptr));
+    Float h = 1.486f;
+    auto cube = BoxTriangles(bs, Translate(Vector3f(0.7f, 0.f, 2.8f)) * RotateY(18) * Transform(), 12, h, h, h);
+    for (int i = 0; i < 12; ++i) prims.push_back(make_shared<GeometricPrimitive>(cube[i], mwhite, nullptr));
+    // the tall block: its "top" face sits at y = h while the sides reach 2h (RayTracing.cpp:166-167)
+    auto block = BoxTriangles(bs, Translate(Vector3f(2.7f, 0.f, 1.0f)) * RotateY(-15) * Transform(), 12, h, h, h * 2);
+    for (int i = 0; i < 12; ++i) prims.push_back(make_shared<GeometricPrimitive>(block[i], i < 10 ? mwhite : mirror, nullptr));
+    bs.scene = make_shared<Scene>(make_shared<BVHAccel>(prims), lights);
+    bs.lookat = LookAt(Point3f(2.5f, 2.5f, 11.8f), Point3f(2.5f, 2.5f, 0.0f), Vector3f(0.0f, 1.0f, 0.0f));
+}
+
+// rand()-driven helpers of the reference's entry file (RayTracing.cpp:30-44).  The reference
+// passes several rand() calls as arguments of one constructor call; the draws below are
+// sequenced last-argument-first, which is what g++ and MSVC do for such calls.
+double Rnd() { return rand() / (RAND_MAX + 1.0); }
+double Rnd(double lo, double hi) { return lo + (hi - lo) * Rnd(); }
+Vector3f RndVec() { double z = Rnd(), y = Rnd(), x = Rnd(); return Vector3f(x, y, z); }
+Vector3f RndVec(double lo, double hi) { double z = Rnd(lo, hi), y = Rnd(lo, hi), x = Rnd(lo, hi); return Vector3f(x, y, z); }
+
+void AddSphere(BuiltScene &bs, std::vector<std::shared_ptr<Primitive>> &prims, const Vector3f &c, Float r, const std::shared_ptr<Material> &m) {
+    Transform o2w = Translate(c) * Transform();
+    const Transform *po = bs.Keep(o2w), *pi = bs.Keep(Inverse(o2w));
+    prims.push_back(make_shared<GeometricPrimitive>(make_shared<Sphere>(po, pi, false, r), m, nullptr));
+}
+
+void BuildSpheres(BuiltScene &bs, bool extended, const std::string &assets) {
+    srand(1);   // glibc's default seed, so repeated builds in one process give the same layout
+    std::vector<std::shared_ptr<Primitive>> prims;
+    AddSphere(bs, prims, Vector3f(0.f, -1000.f, 0.f), 1000.0, Matte(Spectrum(0.5, 0.5, 0.5)));
+    for (int a = -11; a < 11; a++)
+        for (int b = -11; b < 11; b++) {
+            double choose_mat = Rnd();
+            double cz = b + 0.8 * Rnd(), cx = a + 0.8 * Rnd();
+            Point3f center(cx, 0.2, cz);
+            if ((center - Point3f(4, 0.2, 0)).Length() > 1.0) {
+                if (choose_mat < 0.8) {
+                    Vector3f second = RndVec(), first = RndVec();
+                    AddSphere(bs, prims, Vector3f(center), 0.2, Matte(Spectrum(first * second)));
+                } else {
+                    Spectrum albedo = RndVec(0.5, 1);
+                    AddSphere(bs, prims, Vector3f(center), 0.2, make_shared<MirrorMaterial>(Const(albedo)));
+                }
+            }
+        }
+    std::shared_ptr<Material> big = Matte(Spectrum(0.4, 0.2, 0.1));
+    if (extended) {
+        shared_ptr<Texture<Spectrum>> earth = make_shared<ImageTexture<RGBSpectrum, Spectrum>>(
+            make_unique<UVMapping2D>(1.f, 1.f, 0.f, 0.f), assets + "/earthmap.jpg", false, 8.f, ImageWrap::Repeat, 1.f, false);
+        big = make_shared<MatteMaterial>(earth, ConstF(0.0f));
+    }
+    AddSphere(bs, prims, Vector3f(-4, 1, 0), 1.0, big);
+    AddSphere(bs, prims, Vector3f(4, 1, 0), 1.0, make_shared<MirrorMaterial>(Const(Spectrum(0.7, 0.6, 0.5))));
+    if (extended)
+        AddSphere(bs, prims, Vector3f(0, 1, 0), 1.0, make_shared<GlassMaterial>(Const(Spectrum(1.f)), Const(Spectrum(1.f)), ConstF(1.5f)));
+    std::vector<std::shared_ptr<Light>> lights;
+    bs.scene = make_shared<Scene>(make_shared<BVHAccel>(prims), lights);
+    bs.lookat = LookAt(Point3f(13, 2, 3), Point3f(0.f, 0.f, 0.f), Vector3f(0.0f, 1.0f, 0.0f));
+}
+
+void BuildHelmet(BuiltScene &bs, const std::string &assets) {
+    std::vector<std::shared_ptr<Primitive>> prims; std::vector<std::shared_ptr<Light>> lights;
+    std::shared_ptr<Material> m1 = Matte(Spectrum(1.0f, 1.0f, 1.0f));
+    AddCeilingLight(bs, prims, lights, m1, 25.f);
+    Float L = 5;
+    auto room = BoxTriangles(bs, Transform(), 10, L, L, L);
+    for (int i = 0; i < 10; ++i) prims.push_back(make_shared<GeometricPrimitive>(room[i], m1, nullptr));
+    Float ts = 2.5f;
+    Transform o2w = Translate(Vector3f(ts, ts, ts)) * RotateY(-90) * RotateX(-90);
+    bs.loaders.emplace_back(new ModelLoad);
+    ModelLoad &ML = *bs.loaders.back();
+    ML.loadModel(assets + "/DamagedHelmet/glTF/DamagedHelmet.gltf", o2w);
+    if (ML.meshes.empty()) throw std::runtime_error("helmet: could not load " + assets + "/DamagedHelmet/glTF/DamagedHelmet.gltf");
+    ML.buildTextureModel(o2w, prims);
+    bs.scene = make_shared<Scene>(make_shared<BVHAccel>(prims), lights);
+    bs.lookat = LookAt(Point3f(1.f + ts, 0.7f + ts, -1.f + ts), Point3f(-0.5f + ts, -0.2f + ts, 0.3f + ts), Vector3f(0.0f, 1.0f, 0.0f));
+}
+
+// PCG32 (O'Neill 2014), sequence 0xC0FFEE.
+struct Pcg {
+    uint64_t state = 0, inc = 0;
+    explicit Pcg(uint64_t seq) { inc = (seq << 1u) | 1u; next(); state += 0x853c49e6748fea9bULL; next(); }
+    uint32_t next() { uint64_t o = state; state = o * 0x5851f42d4c957f2dULL + inc; uint32_t x = (uint32_t)(((o >> 18u) ^ o) >> 27u); uint32_t r = (uint32_t)(o >> 59u); return (x >> r) | (x << ((~r + 1u) & 31)); }
+    float uniform() { return std::min(0.99999994f, next() * 2.3283064365386963e-10f); }
+};
+void BuildSoup(BuiltScene &bs, int64_t n) {
+    if (n <= 0) n = 100000;
+    auto fs = std::make_unique<FlatScene>();
+    fs->tri_p.resize(9 * (size_t)n); fs->tri_uv.resize(6 * (size_t)n);
+    fs->prim_kind.assign(n, RT_PRIM_TRIANGLE); fs->prim_geom.resize(n); fs->prim_material.assign(n, 0); fs->prim_light.assign(n, -1);
+    Pcg rng(0xC0FFEE);
+    const float duv[6] = {0, 0, 1, 0, 1, 1};
+    for (int64_t i = 0; i < n; ++i) {
+        float c[3]; for (int k = 0; k < 3; ++k) c[k] = 100.f * rng.uniform();
+        for (int v = 0; v < 3; ++v) for (int k = 0; k < 3; ++k) fs->tri_p[9 * i + 3 * v + k] = c[k] + (0.3f * rng.uniform() - 0.15f);
+        memcpy(&fs->tri_uv[6 * i], duv, sizeof(duv));
+        fs->prim_geom[i] = (int32_t)i;
+    }
+    rt_texture t; memset(&t, 0, sizeof(t)); t.kind = RT_TEX_CONST; t.value[0] = t.value[1] = t.value[2] = 0.5f; fs->textures.push_back(t);
+    rt_material m; memset(&m, 0, sizeof(m)); m.kind = RT_MAT_MATTE; m.tex[0] = 0; m.tex[1] = m.tex[2] = m.tex[3] = -1; fs->materials.push_back(m);
+    fs->Bind();
+    std::vector<float> bounds(6 * (size_t)n);
+    rt_prim_bounds(&fs->desc, bounds.data());
+    fs->nodes.resize(2 * (size_t)n); fs->prim_order.resize(n);
+    int32_t nn = 0;
+    if (rt_bvh_build((int32_t)n, bounds.data(), fs->nodes.data(), &nn, fs->prim_order.data()) != 0) throw std::runtime_error("soup: rt_bvh_build failed");
+    fs->nodes.resize(nn); fs->nodes.shrink_to_fit();
+    fs->Bind();
+    bs.flat = std::move(fs);
+    bs.lookat = LookAt(Point3f(-60.f, 50.f, -60.f), Point3f(50.f, 50.f, 50.f), Vector3f(0.0f, 1.0f, 0.0f));
+}
+
+}  // namespace
+
+extern "C" {
+
+struct rth_scene { BuiltScene b; };
+
+const char *rth_last_error(void) { return g_error.c_str(); }
+
+rth_scene *rth_scene_build(const char *name, const char *assets_dir, int64_t param) {
+    std::string nm = name ? name : "", assets = assets_dir ? assets_dir : ".";
+    rth_scene *h = new rth_scene;
+    try {
+        if (nm == "cornell") BuildCornell(h->b);
+        else if (nm == "sphere1") BuildSpheres(h->b, false, assets);
+        else if (nm == "spheres2") BuildSpheres(h->b, true, assets);
+        else if (nm == "helmet") BuildHelmet(h->b, assets);
+        else if (nm == "soup") BuildSoup(h->b, param);
+        else throw std::runtime_error("unknown scene '" + nm + "'");
+        if (!h->b.flat) h->b.flat = FlattenScene(*h->b.scene);
+    } catch (std::exception &e) { g_error = e.what(); delete h; return nullptr; }
+    return h;
+}
+const rt_scene_desc *rth_scene_desc(rth_scene *h) { return &h->b.flat->desc; }
+int rth_scene_camera(rth_scene *h, int width, int height, rt_camera *out) {
+    Transform c2w = Inverse(h->b.lookat);
+    std::unique_ptr<PerspectiveCamera> cam(CreatePerspectiveCamera(c2w, h->b.nearPlane, h->b.fov, width, height));
+    return cam->Describe(out) ? 0 : -1;
+}
+void rth_scene_free(rth_scene *h) { delete h; }
+void rth_register_image(const char *name, int w, int h, const uint8_t *rgb8) { RegisterImage(name, w, h, rgb8); }
+
+// Render a named scene the way the reference's main() does (RayTracing.cpp:410-434): through
+// PathIntegrator::Render, i.e. the drop-in path.  out_sum: w*h*3 floats.
+int rth_render_like_main(rth_scene *h, int width, int height, int strata_x, int strata_y, int max_depth, const char *png_path,
+                         float *out_sum, rt_render_stats *stats) {
+    try {
+        if (!h->b.scene) throw std::runtime_error("scene has no object graph");
+        Transform c2w = Inverse(h->b.lookat);
+        shared_ptr<Camera> cam = shared_ptr<Camera>(CreatePerspectiveCamera(c2w, h->b.nearPlane, h->b.fov, width, height));
+        shared_ptr<Sampler> ss = make_unique<StratifiedSampler>(strata_x, strata_y, true, 1);
+        Bounds2i pixelBounds;
+        auto pi = make_shared<PathIntegrator>(max_depth, cam, ss, pixelBounds, 1.f);
+        pi->outputPath = png_path ? png_path : "";
+        shared_ptr<Integrator> integ = pi;
+        integ->Render(*h->b.scene, width, height);
+        if (out_sum) memcpy(out_sum, pi->lastSum.data(), pi->lastSum.size() * sizeof(float));
+        if (stats) *stats = pi->lastStats;
+    } catch (std::exception &e) { g_error = e.what(); return -1; }
+    return 0;
+}
+
+// Known-answer helpers for the transform code: ops are applied as M = op[0] * op[1] * ... ;
+// kind 0 = Translate(x,y,z), 1 = RotateX(x), 2 = RotateY(x), 3 = RotateZ(x), 4 = Scale(x,y,z).
+int rth_kat_transform(int n_ops, const int *kinds, const float *args, int n_pts, const float *pts, float *out_pts, float *out_m, float *out_minv) {
+    Transform t;
+    for (int i = 0; i < n_ops; ++i) {
+        const float *a = args + 3 * i; Transform o;
+        switch (kinds[i]) { case 0: o = Translate(Vector3f(a[0], a[1], a[2])); break; case 1: o = RotateX(a[0]); break; case 2: o = RotateY(a[0]); break;
+                            case 3: o = RotateZ(a[0]); break; case 4: o = Scale(a[0], a[1], a[2]); break; default: return -1; }
+        t = (i == 0) ? o : t * o;
+    }
+    for (int i = 0; i < n_pts; ++i) { Point3f p = t(Point3f(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2])); out_pts[3 * i] = p.x; out_pts[3 * i + 1] = p.y; out_pts[3 * i + 2] = p.z; }
+    if (out_m) memcpy(out_m, t.GetMatrix().m, 64);
+    if (out_minv) memcpy(out_minv, t.GetInverseMatrix().m, 64);
+    return 0;
+}
+int rth_kat_camera(const float *eye, const float *look, const float *up, float fov, float near_plane, int w, int h, rt_camera *out) {
+    Transform la = LookAt(Point3f(eye[0], eye[1], eye[2]), Point3f(look[0], look[1], look[2]), Vector3f(up[0], up[1], up[2]));
+    std::unique_ptr<PerspectiveCamera> cam(CreatePerspectiveCamera(Inverse(la), near_plane, fov, w, h));
+    return cam->Describe(out) ? 0 : -1;
+}
+
+}  // extern "C"
