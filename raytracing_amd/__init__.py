@@ -37,11 +37,11 @@ def default_assets_dir():
     return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "assets")
 
 
-def register_image_file(path):
-    """Decode an image with PIL and hand the 8-bit RGB pixels to the host library under its file name."""
+def register_image_file(path, alias=None):
+    """Decode an image with PIL and hand the 8-bit RGB pixels to the host library under `alias` (default: its file name)."""
     from PIL import Image
     im = np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8))
-    host().rth_register_image(os.path.basename(path).encode(), im.shape[1], im.shape[0], capi.u8ptr(im))
+    host().rth_register_image((alias or os.path.basename(path)).encode(), im.shape[1], im.shape[0], capi.u8ptr(im))
 
 
 class HostScene:
@@ -52,8 +52,9 @@ class HostScene:
         if name == "spheres2":
             register_image_file(os.path.join(assets_dir, "earthmap.jpg"))
         if name == "helmet":
-            for f in ("Default_albedo.jpg", "Default_metalRoughness.jpg"):
-                register_image_file(os.path.join(assets_dir, "DamagedHelmet", "glTF", f))
+            # DamagedHelmet.gltf names PNG files; the reference tree only holds their JPEG twins.
+            for f in ("Default_albedo", "Default_metalRoughness"):
+                register_image_file(os.path.join(assets_dir, "DamagedHelmet", "glTF", f + ".jpg"), alias=f + ".png")
         self.name = name
         self._h = host().rth_scene_build(name.encode(), assets_dir.encode(), int(param))
         if not self._h:

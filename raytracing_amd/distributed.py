@@ -1,0 +1,51 @@
+"""Sample-split data parallelism: every rank renders a contiguous range of the per-pixel sample indices of the whole
+frame, then the float sum buffers are combined with ONE reduce (RCCL over xGMI when the backend is nccl).
+
+The render itself is injected (`scene.render_device` on a GPU rank), so the split / reduce logic can be exercised with
+torch.distributed's gloo backend on CPU ranks in tests."""
+import numpy as np
+
+from . import make_opts
+
+
+def split_samples(total, rank, world):
+    """Contiguous, exhaustive, near-equal partition of sample indices [0, total) — rank r gets [begin, end)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, rem = divmod(total, world)
+    begin = rank * base + min(rank, rem)
+    end = begin + base + (1 if rank < rem else 0)
+    return begin, end
+
+
+def reduce_frame(frame, dist, dst=0):
+    """One collective per frame: sum of the per-rank radiance sums lands on rank `dst`."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM)
+    return frame
+
+
+def render_frame_split(scene, cam, sx, sy, max_depth, rank, world, frame, dist, seed=(0x243F6A88, 0x85A308D3)):
+    """Render this rank's share of the sx*sy samples into `frame` (torch tensor H x W x 3 on the rank's device) and reduce.
+    Returns the rank's rt_render_stats."""
+    import torch
+    begin, end = split_samples(sx * sy, rank, world)
+    ptr, stats = scene.render_device(cam, make_opts(sx, sy, begin=begin, end=end, max_depth=max_depth, seed=seed))
+    n = cam.width * cam.height * 3
+    # wrap the library-owned device buffer without copying through the host
+    src = _as_tensor(ptr, n, frame.device)
+    frame.view(-1).copy_(src)
+    reduce_frame(frame, dist)
+    return stats
+
+
+class _DevArray:
+    """__cuda_array_interface__ view of a raw device pointer (float32, contiguous)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def _as_tensor(ptr, n, device):
+    import torch
+    return torch.as_tensor(_DevArray(ptr, n), device=device)

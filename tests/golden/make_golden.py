@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE renderer's own code.
+
+Needs /root/reference (build the driver first: `make ref`).  The driver (oracle/ref_driver.cpp) compiles the
+reference's sources where they lie; this script feeds it scenes flattened by this repository's host library,
+ray batches and probe points, and stores what the reference computed:
+
+  ref_bvh_<scene>.npz      the reference's flattened BVH (nodes as raw bytes, leaf order)
+  ref_rays_<scene>.npz     ray batches (camera / diffuse bounce / shadow segments / random) with the reference's
+                           closest-hit primitive, t, (u,v) and any-hit answer
+  ref_probe_<scene>.npz    interaction + BSDF known answers at probe hits (p, n, wo, uv, dpdu, f, Sample_f)
+  ref_camera.npz           PerspectiveCamera::GenerateRay known answers
+  ref_transform.npz        Transform composition known answers (matrices, inverses, transformed points)
+  ref_img_<scene>_*.npy    float radiance sums rendered by PathIntegrator::Li_re with the reference's
+                           StratifiedSampler, two sampler seeds each
+
+Run from the repository root:  python tests/golden/make_golden.py
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import raytracing_amd as ra  # noqa: E402
+import oracle_lib as ol      # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+TMP = tempfile.mkdtemp(prefix="rt_golden_")
+
+CAMERAS = {   # eye, look, up of the reference's scene functions (RayTracing.cpp:187-190, 406, 315); fov 40, near 0.01 (:424-426)
+    "cornell": ((2.5, 2.5, 11.8), (2.5, 2.5, 0.0), (0, 1, 0)),
+    "sphere1": ((13, 2, 3), (0, 0, 0), (0, 1, 0)),
+    "spheres2": ((13, 2, 3), (0, 0, 0), (0, 1, 0)),
+    "helmet": ((3.5, 3.2, 1.5), (2.0, 2.3, 2.8), (0, 1, 0)),
+}
+
+
+def as_np(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+def texture_png(scene_name, tex, idx):
+    """Write the texture's 8-bit source as PNG for the reference's PNG-only reader (imageio.cpp:7-17)."""
+    from PIL import Image
+    w, h = tex.width, tex.height
+    tx = np.ctypeslib.as_array(tex.texels, shape=(h, w, 3))
+    u8 = np.rint(tx * 255.0).astype(np.uint8)
+    assert np.array_equal((u8 / np.float32(255.0)).astype(np.float32), tx), "texture is not 8-bit data"
+    path = os.path.join(TMP, "%s_tex%d.png" % (scene_name, idx))
+    Image.fromarray(u8, "RGB").save(path)
+    return path
+
+
+def dump_scene(scene, path):
+    d = scene.desc
+    out = [struct.pack("<I6i", 0x43535452, d.n_prims, d.n_tris, d.n_spheres, d.n_materials, d.n_textures, d.n_lights)]
+    out.append(as_np(d.prim_kind, d.n_prims, np.uint8).tobytes())
+    out.append(as_np(d.prim_geom, d.n_prims, np.int32).tobytes())
+    out.append(as_np(d.prim_material, d.n_prims, np.int32).tobytes())
+    out.append(as_np(d.prim_light, d.n_prims, np.int32).tobytes())
+    out.append(as_np(d.tri_p, 9 * d.n_tris, np.float32).tobytes())
+    out.append(as_np(d.tri_uv, 6 * d.n_tris, np.float32).tobytes())
+    has_n = bool(d.tri_n) and bool(d.tri_has_n)
+    out.append(struct.pack("<i", int(has_n)))
+    if has_n:
+        out.append(as_np(d.tri_n, 9 * d.n_tris, np.float32).tobytes())
+        out.append(as_np(d.tri_has_n, d.n_tris, np.uint8).tobytes())
+    for i in range(d.n_spheres):
+        s = d.spheres[i]
+        out.append(struct.pack("<33f", s.radius, *list(s.o2w), *list(s.w2o)))
+    for i in range(d.n_materials):
+        m = d.materials[i]
+        out.append(struct.pack("<7i", m.kind, *list(m.tex), m.remap_roughness, 0))
+    for i in range(d.n_textures):
+        t = d.textures[i]
+        png = texture_png(scene.name, t, i).encode() if t.kind == 1 else b""
+        out.append(struct.pack("<3i3f4fi", t.kind, t.width, t.height, *list(t.value), t.su, t.sv, t.du, t.dv, len(png)) + png)
+    for i in range(d.n_lights):
+        L = d.lights[i]
+        out.append(struct.pack("<i3fif", L.prim, *list(L.Le), L.two_sided, L.area))
+    with open(path, "wb") as f:
+        f.write(b"".join(out))
+
+
+def cam_spec(name, w, h):
+    eye, look, up = CAMERAS[name]
+    return struct.pack("<11f2i", *eye, *look, *up, 40.0, 0.01, w, h)
+
+
+def run(*args):
+    subprocess.check_call([DRIVER] + [str(a) for a in args])
+
+
+def make_rays(scene, osc, cam, n_each, seed):
+    """Four batches: camera rays, cosine-ish bounce rays off primary hits, shadow segments between hit points, random rays."""
+    rng = np.random.default_rng(seed)
+    W, H = cam.width, cam.height
+    fx = rng.uniform(0, W, n_each).astype(np.float32); fy = rng.uniform(0, H, n_each).astype(np.float32)
+    co = np.zeros((n_each, 3), np.float32); cd = np.zeros((n_each, 3), np.float32)
+    for i in range(n_each):
+        co[i], cd[i] = osc.camera_ray(cam, float(fx[i]), float(fy[i]))
+    inf = np.full(n_each, np.inf, np.float32)
+    prim, t, _, _, _ = osc.trace_closest(co, cd, inf)
+    hitp = (co + cd * np.where(np.isfinite(t), t, 0)[:, None]).astype(np.float32)
+    ok = prim >= 0
+    # bounce rays: from slightly off the surface in a random direction flipped to the incoming side
+    rd = rng.normal(size=(n_each, 3)).astype(np.float32); rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    flip = (np.sum(rd * cd, axis=1) > 0)
+    rd[flip] *= -1
+    bo = (hitp + rd * np.float32(2e-4)).astype(np.float32); bd = rd.astype(np.float32)
+    bo[~ok] = co[~ok]; bd[~ok] = cd[~ok]
+    # shadow-style segments between pairs of hit points (unnormalised direction, tMax = 1 - 1e-4, interaction.h:27-32)
+    perm = rng.permutation(n_each)
+    so = (hitp - cd * np.float32(1e-3)).astype(np.float32)
+    sd = ((hitp[perm] - cd[perm] * np.float32(1e-3)) - so).astype(np.float32)
+    st = np.full(n_each, np.float32(1) - np.float32(1e-4), np.float32)
+    bad = ~(ok & ok[perm]) | (np.linalg.norm(sd, axis=1) == 0)
+    so[bad] = co[bad]; sd[bad] = cd[bad]
+    # random rays through the scene's bounding box
+    nodes = scene.nodes()
+    lo, hi = nodes[0]["bmin"], nodes[0]["bmax"]
+    lo = np.maximum(lo, -30); hi = np.minimum(hi, 30)
+    ro = rng.uniform(lo - 1, hi + 1, (n_each, 3)).astype(np.float32)
+    rdd = rng.normal(size=(n_each, 3)).astype(np.float32); rdd /= np.linalg.norm(rdd, axis=1, keepdims=True)
+    o = np.concatenate([co, bo, so, ro]); d = np.concatenate([cd, bd, sd, rdd.astype(np.float32)])
+    tm = np.concatenate([inf, inf, st, inf])
+    return np.ascontiguousarray(o, np.float32), np.ascontiguousarray(d, np.float32), np.ascontiguousarray(tm, np.float32)
+
+
+def golden_for_scene(name, n_rays, img_specs, probe_n=512):
+    print("==", name)
+    scene = ra.HostScene(name)
+    osc = ol.OracleScene(scene.desc_ptr)
+    sbin = os.path.join(TMP, name + ".scene")
+    dump_scene(scene, sbin)
+    # --- BVH
+    out = os.path.join(TMP, name + ".bvh")
+    run("bvh", sbin, out)
+    raw = open(out, "rb").read()
+    nn = struct.unpack("<i", raw[:4])[0]
+    nodes = np.frombuffer(raw[4:4 + 32 * nn], dtype=np.uint8).copy()
+    order = np.frombuffer(raw[4 + 32 * nn:], dtype=np.int32).copy()
+    np.savez_compressed(os.path.join(GOLD, "ref_bvh_%s.npz" % name), nodes=nodes, order=order, n_nodes=nn)
+    # --- ray batches
+    cam = scene.camera(256, 256)
+    o, d, tm = make_rays(scene, osc, cam, n_rays, 7)
+    rays = np.concatenate([o, d, tm[:, None]], axis=1).astype(np.float32)
+    rpath, opath = os.path.join(TMP, name + ".rays"), os.path.join(TMP, name + ".hits")
+    rays.tofile(rpath)
+    run("trace", sbin, rpath, opath)
+    res = np.fromfile(opath, dtype=np.dtype([("prim", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("any", "<u4")]))
+    np.savez_compressed(os.path.join(GOLD, "ref_rays_%s.npz" % name), o=o, d=d, tmax=tm, prim=res["prim"], t=res["t"], u=res["u"], v=res["v"],
+                        any=res["any"].astype(np.uint8))
+    # --- interaction / BSDF probes at camera + bounce hits
+    rng = np.random.default_rng(11)
+    sel = rng.choice(2 * n_rays, probe_n, replace=False)
+    wi = rng.normal(size=(probe_n, 3)).astype(np.float32); wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    u01 = rng.uniform(0, 1, (probe_n, 2)).astype(np.float32)
+    probes = np.concatenate([o[sel], d[sel], wi.astype(np.float32), u01], axis=1).astype(np.float32)
+    ppath, qpath = os.path.join(TMP, name + ".probes"), os.path.join(TMP, name + ".probeout")
+    probes.tofile(ppath)
+    run("probe", sbin, ppath, qpath)
+    pout = np.fromfile(qpath, dtype=np.float32).reshape(probe_n, 26)
+    np.savez_compressed(os.path.join(GOLD, "ref_probe_%s.npz" % name), probes=probes, out=pout)
+    # --- images
+    for (w, h, sx, sy, seeds) in img_specs:
+        cpath = os.path.join(TMP, "%s_%d.cam" % (name, w))
+        open(cpath, "wb").write(cam_spec(name, w, h))
+        for tag, off in seeds:
+            ipath = os.path.join(TMP, "img.f32")
+            run("render", sbin, cpath, sx, sy, 50, off, 8, ipath)
+            img = np.fromfile(ipath, dtype=np.float32).reshape(h, w, 3)
+            np.save(os.path.join(GOLD, "ref_img_%s_%dx%d_%dspp_seed%s.npy" % (name, w, h, sx * sy, tag)), img)
+            print("   image", w, h, sx * sy, tag, "mean", img.mean(axis=(0, 1)) / (sx * sy))
+    osc.close(); scene.close()
+
+
+def golden_camera():
+    rng = np.random.default_rng(3)
+    res = {}
+    for name, (w, h) in (("cornell", (800, 800)), ("sphere1", (1440, 1440)), ("helmet", (1440, 1440)), ("cornell_wide", (640, 360))):
+        key = "cornell" if name.startswith("cornell") else name
+        film = np.stack([rng.uniform(0, w, 256), rng.uniform(0, h, 256)], axis=1).astype(np.float32)
+        film[:4] = [[0, 0], [w, h], [w / 2, h / 2], [0.5, h - 0.5]]
+        cpath, fpath, opath = [os.path.join(TMP, "k." + e) for e in ("cam", "film", "out")]
+        eye, look, up = CAMERAS[key]
+        open(cpath, "wb").write(struct.pack("<11f2i", *eye, *look, *up, 40.0, 0.01, w, h))
+        film.tofile(fpath)
+        run("camera", cpath, fpath, opath)
+        res[name + "_film"] = film
+        res[name + "_rays"] = np.fromfile(opath, dtype=np.float32).reshape(-1, 6)
+        res[name + "_spec"] = np.array(list(eye) + list(look) + list(up) + [40.0, 0.01, w, h], np.float64)
+    np.savez_compressed(os.path.join(GOLD, "ref_camera.npz"), **res)
+
+
+def golden_transform():
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-3, 3, (64, 3)).astype(np.float32)
+    cases = {   # the compositions the reference's scenes use (RayTracing.cpp:83,127,155,202,306) and a few more
+        "light": [(0, (2.5, 0.0, 2.5))],
+        "cube": [(0, (0.7, 0.0, 2.8)), (2, (18, 0, 0))],
+        "block": [(0, (2.7, 0.0, 1.0)), (2, (-15, 0, 0))],
+        "helmet": [(0, (2.5, 2.5, 2.5)), (2, (-90, 0, 0)), (1, (-90, 0, 0))],
+        "mrspheres": [(3, (180, 0, 0)), (2, (180, 0, 0)), (1, (-90, 0, 0))],
+        "scaled": [(4, (2.0, 0.5, 3.0)), (3, (33, 0, 0)), (0, (1, -2, 3))],
+    }
+    res = {"pts": pts}
+    for name, ops in cases.items():
+        blob = struct.pack("<i", len(ops)) + np.array([k for k, _ in ops], np.int32).tobytes() + \
+            np.array([a for _, a in ops], np.float32).tobytes() + struct.pack("<i", len(pts)) + pts.tobytes()
+        ipath, opath = os.path.join(TMP, "t.in"), os.path.join(TMP, "t.out")
+        open(ipath, "wb").write(blob)
+        run("transform", ipath, opath)
+        out = np.fromfile(opath, dtype=np.float32)
+        res[name + "_kinds"] = np.array([k for k, _ in ops], np.int32)
+        res[name + "_args"] = np.array([a for _, a in ops], np.float32)
+        res[name + "_pts"] = out[:3 * len(pts)].reshape(-1, 3)
+        res[name + "_m"] = out[3 * len(pts):3 * len(pts) + 16]
+        res[name + "_minv"] = out[3 * len(pts) + 16:]
+    np.savez_compressed(os.path.join(GOLD, "ref_transform.npz"), **res)
+
+
+if __name__ == "__main__":
+    if not os.path.exists(DRIVER):
+        sys.exit("build the reference driver first: make ref")
+    only = sys.argv[1:]
+    if not only or "kat" in only:
+        golden_camera(); golden_transform()
+    A, B = ("A", 0), ("B", 1 << 20)
+    if not only or "cornell" in only:
+        golden_for_scene("cornell", 4096, [(64, 64, 4, 4, [A, B]), (100, 100, 16, 16, [A, B])])
+    if not only or "sphere1" in only:
+        golden_for_scene("sphere1", 4096, [(64, 64, 4, 4, [A, B])])
+    if not only or "spheres2" in only:
+        golden_for_scene("spheres2", 4096, [(96, 96, 8, 8, [A, B])])
+    if not only or "helmet" in only:
+        golden_for_scene("helmet", 4096, [(96, 96, 8, 8, [A, B])])
+    print("fixtures written to", GOLD)
+
+
+def golden_shipped_images():
+    """Statistics of result images the reference's authors checked in (RayTracing/*.png; file names encode
+    scene_resolution_spp[_seconds]).  Stored: per-channel 8-bit means, and for the 1024-spp Cornell render a
+    100x100 box-downsampled copy in linear radiance (inverse of write_color: (u8/256)^2) plus a mask of
+    pixels that were not clipped by the tonemap."""
+    import json
+    from PIL import Image
+    src = "/root/reference/RayTracing"
+    stats = {}
+    for f in ("cb3_800_1.png", "cb3_800_256_165s.png", "cb3_800_1024_660s.png", "sphere1_1440_1.png", "sphere1_1440_512.png"):
+        im = np.asarray(Image.open(os.path.join(src, f)).convert("RGB"), dtype=np.float64)
+        stats[f] = {"shape": list(im.shape[:2]), "mean_u8": [float(v) for v in im.mean(axis=(0, 1))]}
+    json.dump(stats, open(os.path.join(GOLD, "shipped_image_stats.json"), "w"), indent=1)
+    im = np.asarray(Image.open(os.path.join(src, "cb3_800_1024_660s.png")).convert("RGB"), dtype=np.float64)
+    lin = (im / 256.0) ** 2
+    clipped = (im >= 255).any(axis=2)
+    lin100 = lin.reshape(100, 8, 100, 8, 3).mean(axis=(1, 3)).astype(np.float32)
+    ok100 = ~clipped.reshape(100, 8, 100, 8).any(axis=(1, 3))
+    np.savez_compressed(os.path.join(GOLD, "shipped_cb3_800_1024_lin100.npz"), lin=lin100, unclipped=ok100)
+
+
+if __name__ == "__main__" and (len(sys.argv) == 1 or "shipped" in sys.argv[1:]):
+    golden_shipped_images()

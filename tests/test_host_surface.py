@@ -1,0 +1,178 @@
+"""Host side of the product (no GPU needed): the C-ABI library loads and exports every symbol of include/rt_amd.h,
+the BVH builder reproduces the reference's tree, the transform / camera code reproduces the reference's matrices,
+the scene scripts reproduce the reference's scenes, tonemap, PNG I/O and the glTF reader."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import raytracing_amd as ra
+from raytracing_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(capi.RT_AMD_SYMBOLS), declared ^ set(capi.RT_AMD_SYMBOLS)
+    lib = ra.rt()
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert b"gfx950" in lib.rt_version()
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(capi.BvhNode) == 32
+    assert C.sizeof(capi.Sphere) == 132
+    assert C.sizeof(capi.Material) == 28
+    assert C.sizeof(capi.Light) == 24
+    assert C.sizeof(capi.Camera) == 136
+    assert C.sizeof(capi.RenderOpts) == 36
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """Without a HIP device rt_init must fail with a message; with one it must succeed.  Either way nothing renders on the CPU."""
+    ctxp = C.c_void_p()
+    rc = ra.rt().rt_init(0, C.byref(ctxp))
+    if rc == 0:
+        ra.rt().rt_shutdown(ctxp)
+    else:
+        assert rc < 0 and b"HIP" in ra.rt().rt_last_error(None)
+
+
+@pytest.mark.parametrize("name", ["cornell", "sphere1", "spheres2", "helmet"])
+def test_product_bvh_builder_reproduces_reference_tree(name, host_scene, gold_dir):
+    g = np.load(os.path.join(gold_dir, "ref_bvh_%s.npz" % name))
+    s = host_scene(name)
+    assert s.nodes().tobytes() == g["nodes"].tobytes()
+    assert np.array_equal(s.prim_order(), g["order"])
+    # rt_bvh_build called directly on rt_prim_bounds gives the same tree
+    nodes, order = ra.bvh_build(ra.prim_bounds(s.desc_ptr))
+    assert nodes.tobytes() == g["nodes"].tobytes() and np.array_equal(order, g["order"])
+
+
+def test_bvh_builder_edge_cases():
+    rng = np.random.default_rng(0)
+    import oracle_lib as ol
+    # one primitive, coincident centroids (multi-primitive leaf), many ties on one axis, random
+    cases = [np.array([[0, 0, 0, 1, 1, 1]], np.float32),
+             np.tile(np.array([[0, 0, 0, 1, 1, 1]], np.float32), (5, 1)),
+             np.concatenate([np.tile(np.array([[0, 0, 0, 1, 1, 1]], np.float32), (7, 1)), np.array([[9, 0, 0, 10, 1, 1]], np.float32)]),
+             np.concatenate([rng.uniform(0, 10, (4000, 3)), rng.uniform(10, 11, (4000, 3))], axis=1).astype(np.float32)]
+    lo = rng.integers(0, 4, (3000, 3)).astype(np.float32)
+    cases.append(np.concatenate([lo, lo + 1], axis=1))
+    for b in cases:
+        n1, o1 = ra.bvh_build(b)
+        n2, o2 = ol.bvh_build(b)
+        assert n1.tobytes() == n2.tobytes() and np.array_equal(o1, o2)
+        assert sorted(o1.tolist()) == list(range(len(b)))
+        leaves = n1[n1["nprim"] > 0]
+        assert leaves["nprim"].sum() == len(b)
+
+
+def test_transform_known_answers(gold_dir):
+    g = np.load(os.path.join(gold_dir, "ref_transform.npz"))
+    pts = np.ascontiguousarray(g["pts"], np.float32)
+    for name in ("light", "cube", "block", "helmet", "mrspheres", "scaled"):
+        kinds = np.ascontiguousarray(g[name + "_kinds"], np.int32); args = np.ascontiguousarray(g[name + "_args"], np.float32)
+        out = np.zeros_like(pts); m = np.zeros(16, np.float32); mi = np.zeros(16, np.float32)
+        rc = ra.host().rth_kat_transform(len(kinds), kinds.ctypes.data_as(C.POINTER(C.c_int)), capi.fptr(args), len(pts), capi.fptr(pts),
+                                         capi.fptr(out), capi.fptr(m), capi.fptr(mi))
+        assert rc == 0
+        assert np.array_equal(m, g[name + "_m"]) and np.array_equal(mi, g[name + "_minv"]), name
+        assert np.array_equal(out, g[name + "_pts"]), name
+
+
+def test_camera_known_answers(gold_dir):
+    """LookAt + Inverse + Perspective + raster transforms of the host surface, checked through the oracle's GenerateRay."""
+    import oracle_lib as ol
+    g = np.load(os.path.join(gold_dir, "ref_camera.npz"))
+    for name in ("cornell", "sphere1", "helmet", "cornell_wide"):
+        spec = g[name + "_spec"]
+        eye, look, up = [np.ascontiguousarray(spec[i:i + 3], np.float32) for i in (0, 3, 6)]
+        cam = capi.Camera()
+        rc = ra.host().rth_kat_camera(capi.fptr(eye), capi.fptr(look), capi.fptr(up), float(spec[9]), float(spec[10]), int(spec[11]), int(spec[12]),
+                                      C.byref(cam))
+        assert rc == 0
+        film, rays = g[name + "_film"], g[name + "_rays"]
+        for i in range(len(film)):
+            o = np.zeros(3, np.float32); d = np.zeros(3, np.float32)
+            ol.lib().orc_camera_ray(C.byref(cam), float(film[i, 0]), float(film[i, 1]), capi.fptr(o), capi.fptr(d))
+            assert np.array_equal(np.concatenate([o, d]), rays[i]), (name, i)
+
+
+def test_scene_contents(host_scene):
+    c = host_scene("cornell").desc
+    assert (c.n_prims, c.n_tris, c.n_nodes, c.n_lights) == (36, 36, 43, 2)
+    s = host_scene("sphere1").desc
+    assert (s.n_prims, s.n_spheres, s.n_nodes, s.n_lights) == (483, 483, 965, 0)
+    h = host_scene("helmet").desc
+    assert (h.n_prims, h.n_nodes, h.n_lights) == (15464, 30077, 2)
+    tex = [h.textures[i] for i in range(h.n_textures)]
+    assert sum(1 for t in tex if t.kind == 1 and t.width == 2048 and t.height == 2048) == 2
+    light = c.lights[0]
+    assert abs(light.area - 0.5) < 1e-6 and list(light.Le) == [20.0, 20.0, 20.0]
+
+
+def test_soup_scene_is_deterministic_and_valid(host_scene):
+    a = ra.HostScene("soup", 20000); b = host_scene("soup", 20000)
+    assert a.nodes().tobytes() == b.nodes().tobytes()
+    assert np.array_equal(a.tri_p(), b.tri_p())
+    n = a.nodes()
+    assert len(n) == 2 * 20000 - 1 and sorted(a.prim_order().tolist()) == list(range(20000))
+    a.close()
+
+
+def test_tonemap_matches_write_color():
+    import oracle_lib as ol
+    rng = np.random.default_rng(1)
+    s = (rng.uniform(0, 3, (16, 16, 3)) ** 3).astype(np.float32) * 7
+    s[0, 0] = [np.nan, -1.0, 1e9]; s[0, 1] = [0.0, 7 * 0.998, 7.0]
+    out = ra.tonemap_u8(s, 7)
+    assert np.array_equal(out, ol.tonemap_u8(s, 7))
+    mean = np.nan_to_num(s / np.float32(7), nan=0.0)
+    want = (256 * np.clip(np.sqrt(np.maximum(mean, 0)), 0, 0.999)).astype(np.int32)
+    assert np.abs(out.astype(np.int32) - want).max() <= 1
+    assert out[0, 0, 0] == 0 and out[0, 0, 2] == 255
+
+
+def test_png_roundtrip_and_gltf(tmp_path, host_scene):
+    from PIL import Image
+    rng = np.random.default_rng(2)
+    px = rng.integers(0, 256, (33, 47, 3), dtype=np.uint8)
+    p = str(tmp_path / "t.png")
+    Image.fromarray(px, "RGB").save(p)
+    # a texture scene that loads this PNG through the host library's own decoder would need a scene script; the decoder is
+    # exercised through the helmet scene's registered images and here through PIL reading what WritePNG produced by a render.
+    h = host_scene("helmet")
+    tri = h.tri_p()
+    assert tri.shape[0] == 15464 - 0 and np.isfinite(tri).all()
+    # helmet vertices sit inside the 5-unit box after Translate(2.5)*RotateY(-90)*RotateX(-90)
+    helmet = tri[12:]
+    assert helmet.min() > 1.0 and helmet.max() < 4.0
+
+
+def test_oracle_matches_authors_shipped_render(host_scene, oracle_scene, gold_dir):
+    """End-to-end pin on the scene script + estimator: the 1024-spp Cornell image the reference's authors checked in
+    (RayTracing/cb3_800_1024_660s.png), box-downsampled to 100x100 in linear radiance.  The shipped render came from the
+    multi-threaded loop whose global `perfectspecular` flag races (integrator.cpp:235,331), which leaks a little extra
+    emission into other threads' paths, so its mean is slightly higher; 3 % bounds that."""
+    g = np.load(os.path.join(gold_dir, "shipped_cb3_800_1024_lin100.npz"))
+    cam = host_scene("cornell").camera(100, 100)
+    img, _ = oracle_scene("cornell").render(cam, ra.make_opts(16, 16), mode=0)
+    img = img / 256
+    m = g["unclipped"]
+    ratio = img[m].mean(axis=0) / g["lin"][m].mean(axis=0)
+    assert np.all(np.abs(ratio - 1) < 0.03), ratio
+    rmse = np.sqrt((((img - g["lin"])[m]) ** 2).mean(axis=0))
+    assert np.all(rmse < 0.02), rmse
+    stats = json.load(open(os.path.join(gold_dir, "shipped_image_stats.json")))
+    cam8 = host_scene("cornell").camera(800, 800)
+    import oracle_lib as ol
+    i8, _ = oracle_scene("cornell").render(cam8, ra.make_opts(1, 1), mode=0)
+    u8 = ol.tonemap_u8(i8, 1).reshape(-1, 3).mean(axis=0)
+    assert np.all(np.abs(u8 / np.array(stats["cb3_800_1.png"]["mean_u8"]) - 1) < 0.01)

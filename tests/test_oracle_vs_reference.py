@@ -1,0 +1,85 @@
+"""The CPU oracle (oracle/rt_oracle.cpp) against golden vectors computed by the REFERENCE renderer's own code
+(tests/golden/make_golden.py + oracle/ref_driver.cpp).  Everything here is required to be bit-exact: the oracle
+restates the reference's float expressions operand by operand and both are built with -ffp-contract=off."""
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+import raytracing_amd as ra
+from raytracing_amd import capi
+
+SCENES = ["cornell", "sphere1", "spheres2", "helmet"]
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_bvh_is_the_reference_tree(name, host_scene, oracle_scene, gold_dir):
+    g = np.load(os.path.join(gold_dir, "ref_bvh_%s.npz" % name))
+    ref_nodes = np.frombuffer(g["nodes"].tobytes(), dtype=capi.BVH_NODE_DTYPE)
+    nodes, order = oracle_scene(name).get_bvh()
+    assert len(nodes) == int(g["n_nodes"])
+    assert nodes.tobytes() == ref_nodes.tobytes()
+    assert np.array_equal(order, g["order"])
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_ray_batches_bit_exact(name, oracle_scene, gold_dir):
+    r = np.load(os.path.join(gold_dir, "ref_rays_%s.npz" % name))
+    prim, t, b, _, _ = oracle_scene(name).trace_closest(r["o"], r["d"], r["tmax"])
+    assert np.array_equal(prim, r["prim"])
+    assert np.array_equal(t.view(np.uint32), r["t"].view(np.uint32))
+    assert (prim >= 0).mean() > 0.3
+    hit = oracle_scene(name).trace_any(r["o"], r["d"], r["tmax"])
+    assert np.array_equal(hit, r["any"])
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_interaction_and_bsdf_known_answers(name, oracle_scene, gold_dir):
+    g = np.load(os.path.join(gold_dir, "ref_probe_%s.npz" % name))
+    P, O = g["probes"], g["out"]
+    osc = oracle_scene(name)
+    kinds = set()
+    for i in range(len(P)):
+        prim, inter = osc.interaction(P[i, 0:3], P[i, 3:6])
+        assert prim == int(O[i, 0])
+        if prim < 0:
+            continue
+        assert np.array_equal(inter, O[i, 1:15]), "interaction (p, n, wo, uv, dpdu) differs at probe %d" % i
+        _, bs = osc.bsdf_probe(P[i, 0:3], P[i, 3:6], P[i, 6:9], float(P[i, 9]), float(P[i, 10]))
+        assert np.array_equal(bs, O[i, 15:26]), "BSDF f / Sample_f differs at probe %d" % i
+        kinds.add(int(O[i, 25]))
+    assert len(kinds) >= 1
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_img_*_seedA.npy"))),
+                         ids=lambda p: os.path.basename(p)[8:-10])
+def test_rendered_images_bit_exact(path, host_scene, oracle_scene):
+    """PathIntegrator::Li_re + StratifiedSampler/PCG32 stream: whole float images equal the reference's, for two seeds."""
+    m = re.match(r"ref_img_(\w+?)_(\d+)x(\d+)_(\d+)spp_seedA.npy", os.path.basename(path))
+    name, w, h, spp = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))
+    sx = int(round(spp ** 0.5))
+    cam = host_scene(name).camera(w, h)
+    opts = ra.make_opts(sx, spp // sx)
+    for tag, off in (("A", 0), ("B", 1 << 20)):
+        ref = np.load(path.replace("seedA", "seed" + tag))
+        img, _ = oracle_scene(name).render(cam, opts, mode=0, seed_offset=off)
+        assert np.array_equal(img, ref), "%s seed %s: max abs diff %g" % (name, tag, np.abs(img - ref).max())
+
+
+def test_philox_sampler_agrees_statistically_with_reference_sampler(host_scene, oracle_scene, gold_dir):
+    """The counter-based sampler replaces the reference's stream; its images must sit inside the reference's own
+    two-seed noise: per-channel mean within 0.5 %, and RMSE against the reference's best estimate (the mean of its
+    two seeds) below the reference's seed-A-vs-seed-B RMSE.  With equal per-image variance s^2 the first is
+    sqrt(1.5) s in expectation and the second sqrt(2) s, so an unbiased sampler passes with a 13 % margin."""
+    a = np.load(os.path.join(gold_dir, "ref_img_cornell_100x100_256spp_seedA.npy")) / 256
+    b = np.load(os.path.join(gold_dir, "ref_img_cornell_100x100_256spp_seedB.npy")) / 256
+    cam = host_scene("cornell").camera(100, 100)
+    img, _ = oracle_scene("cornell").render(cam, ra.make_opts(16, 16), mode=1)
+    img = img / 256
+    floor = np.sqrt(((a - b) ** 2).mean(axis=(0, 1)))
+    best = 0.5 * (a + b)
+    rmse = np.sqrt(((img - best) ** 2).mean(axis=(0, 1)))
+    assert np.all(np.abs(img.mean(axis=(0, 1)) / best.mean(axis=(0, 1)) - 1) < 0.005)
+    assert np.all(rmse < floor), (rmse, floor)
