@@ -64,9 +64,12 @@ def test_trace_edge_cases(device_scene):
     assert prim.shape == (0,)
     o = np.array([[2.5, 2.5, 11.8]], np.float32); d = np.array([[0, 0, -1]], np.float32)
     prim, t, _ = ds.trace_closest(o, d, np.array([np.inf], np.float32))
-    assert prim[0] >= 0 and abs(t[0] - 11.8) < 1e-4            # the back wall at z = 0
+    assert prim[0] == 35 and abs(t[0] - 9.31517) < 1e-4        # the mirror face of the tall block
     prim, t, _ = ds.trace_closest(o, d, np.array([1.0], np.float32))
     assert prim[0] == -1 and t[0] == 1.0                       # tMax respected, t returns tMax on a miss
+    up = np.array([[-2.2, 2.0, -11.8]], np.float32)
+    prim, t, _ = ds.trace_closest(o, up, np.array([np.inf], np.float32))
+    assert prim[0] >= 0 and abs(t[0] - 1.0) < 1e-5             # unnormalised direction: the back wall z = 0 is at t = 1
     prim, t, _ = ds.trace_closest(o, -d, np.array([np.inf], np.float32))
     assert prim[0] == -1
 
