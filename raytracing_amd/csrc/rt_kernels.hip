@@ -32,19 +32,20 @@
     } while (0)
 
 #define RT_NUM_CLASSES 6
-#define RT_COUNTER_WORDS 32
+#define RT_SEG_BLOCKS 1024      // persistent grid of every wavefront kernel == number of queue segments
+#define RT_SEG_PER_THREAD (RT_SEG_BLOCKS / RT_BLOCK)
 
-// Per-bounce device counters (all zeroed once per pass).
-struct BounceCounters {
-    uint32_t n_queue;                   // paths entering this bounce
-    uint32_t n_shadow;                  // shadow rays produced by this bounce
-    uint32_t cls[RT_NUM_CLASSES];       // paths per material class
-    uint32_t fetch_extend, fetch_shadow;
-    uint32_t fetch_cls[RT_NUM_CLASSES];
-    uint32_t stack_overflow;
-    uint32_t pad[RT_COUNTER_WORDS - 5 - 2 * RT_NUM_CLASSES];
+// Queues are segmented: block b of a producer kernel appends only to segment b (positions
+// [b*segcap, b*segcap + count[b])) using a block-local LDS counter, and publishes count[b] with a plain store when it
+// is done.  A consumer kernel turns the RT_SEG_BLOCKS counts into a prefix sum, takes an equal share of the
+// concatenated items and walks the segments.  No global atomics, no contended cache line, and the result does not
+// depend on scheduling.
+struct BounceCounts {
+    uint32_t queue[RT_SEG_BLOCKS];                    // paths entering this bounce (written by the previous bounce's shading)
+    uint32_t shadow[RT_SEG_BLOCKS];                   // shadow rays produced by this bounce
+    uint32_t cls[RT_NUM_CLASSES][RT_SEG_BLOCKS];      // paths per material class
 };
-static_assert(sizeof(BounceCounters) == RT_COUNTER_WORDS * 4, "counter block size");
+struct BounceStats { uint32_t n_queue, n_shadow, stack_overflow, pad; };
 
 struct PathQueue {   // SoA, capacity = cap
     float *ox, *oy, *oz, *dx, *dy, *dz, *tr, *tg, *tb;
@@ -69,21 +70,49 @@ __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi
 __device__ __forceinline__ uint32_t prefix_in_mask(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-// Wave-aggregated append: every lane with `want` gets a unique position in a queue whose size lives at *counter.
-__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t *counter) {
+// Exclusive prefix sum of RT_SEG_BLOCKS segment counts into s_prefix[0..RT_SEG_BLOCKS] (last entry = total).
+__device__ __forceinline__ uint32_t segment_prefix(const uint32_t *__restrict__ counts, uint32_t *s_prefix, uint32_t *s_wave) {
+    uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t v[RT_SEG_PER_THREAD], sum = 0;
+#pragma unroll
+    for (int k = 0; k < RT_SEG_PER_THREAD; ++k) { v[k] = counts[t * RT_SEG_PER_THREAD + k]; sum += v[k]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t y = __shfl_up(incl, off); if (lane >= (uint32_t)off) incl += y; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; ++w) base += s_wave[w];
+    uint32_t run = base + incl - sum;
+#pragma unroll
+    for (int k = 0; k < RT_SEG_PER_THREAD; ++k) { s_prefix[t * RT_SEG_PER_THREAD + k] = run; run += v[k]; }
+    if (t == RT_BLOCK - 1) s_prefix[RT_SEG_BLOCKS] = run;
+    __syncthreads();
+    return s_prefix[RT_SEG_BLOCKS];
+}
+// This block's share [lo, hi) of `total` concatenated items (multiples of the wave size).
+__device__ __forceinline__ void block_share(uint32_t total, uint32_t &lo, uint32_t &hi) {
+    uint32_t share = (total + RT_SEG_BLOCKS - 1) / RT_SEG_BLOCKS;
+    share = (share + RT_WAVE - 1) & ~(uint32_t)(RT_WAVE - 1);
+    uint64_t l = (uint64_t)blockIdx.x * share;
+    lo = (uint32_t)(l < total ? l : total);
+    hi = (uint32_t)((l + share) < total ? (l + share) : total);
+}
+// Segment that holds concatenated index g (s_prefix[s] <= g < s_prefix[s+1]); g < total.
+__device__ __forceinline__ uint32_t segment_of(const uint32_t *s_prefix, uint32_t g) {
+    uint32_t lo = 0, hi = RT_SEG_BLOCKS;   // invariant: s_prefix[lo] <= g < s_prefix[hi]
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (s_prefix[mid] <= g) lo = mid; else hi = mid; }
+    return lo;
+}
+// Append within this block's segment: wave ballot + one LDS atomic per wave.  Returns the position inside the segment.
+__device__ __forceinline__ uint32_t block_append(bool want, uint32_t *s_counter) {
     uint64_t mask = __ballot(want);
     if (mask == 0) return 0;
     uint32_t n = __popcll(mask), base = 0;
     int leader = __ffsll((unsigned long long)mask) - 1;
-    if ((int)lane_id() == leader) base = atomicAdd(counter, n);
+    if ((int)lane_id() == leader) base = atomicAdd(s_counter, n);
     base = __shfl(base, leader);
     return base + prefix_in_mask(mask);
-}
-// Each wave of a persistent grid takes the next 64 work items.
-__device__ __forceinline__ uint32_t wave_fetch(uint32_t *fetch) {
-    uint32_t base = 0;
-    if (lane_id() == 0) base = atomicAdd(fetch, RT_WAVE);
-    return __builtin_amdgcn_readfirstlane(base);
 }
 
 // ----------------------------------------------------- batch trace kernels --
@@ -139,9 +168,10 @@ __device__ __forceinline__ F3 xf_point_proj(const float *m, F3 p) {   // Transfo
     return f3(inv * xp, inv * yp, inv * zp);
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderParams rp, PathQueue q, float4 *lbuf, BounceCounters *counters) {
-    uint32_t n = rp.n_paths;
-    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < n; id += gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderParams rp, PathQueue q, uint32_t segcap, float4 *lbuf, BounceCounts *counts) {
+    uint32_t n = rp.n_paths, lo, hi;
+    block_share(n, lo, hi);
+    for (uint32_t id = lo + threadIdx.x; id < hi; id += RT_BLOCK) {
         uint32_t pixel = id / (uint32_t)rp.spb, sample = (uint32_t)rp.sample0 + id % (uint32_t)rp.spb;
         uint32_t c0 = pixel, c1 = sample, c2 = 0xFFFFFFFFu, c3 = 0;
         philox4x32(c0, c1, c2, c3, rp.k0, rp.k1);
@@ -157,29 +187,39 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderParams rp, PathQueue 
         F3 dir = normalize3(pCamera);
         F3 o = xf_point_proj(rp.c2w, f3(0.f, 0.f, 0.f));
         F3 d = xf_vector(rp.c2w, dir);
-        q.ox[id] = o.x; q.oy[id] = o.y; q.oz[id] = o.z; q.dx[id] = d.x; q.dy[id] = d.y; q.dz[id] = d.z;
-        q.tr[id] = 1.f; q.tg[id] = 1.f; q.tb[id] = 1.f; q.id[id] = id; q.state[id] = 0;
+        uint32_t pos = blockIdx.x * segcap + (id - lo);
+        q.ox[pos] = o.x; q.oy[pos] = o.y; q.oz[pos] = o.z; q.dx[pos] = d.x; q.dy[pos] = d.y; q.dz[pos] = d.z;
+        q.tr[pos] = 1.f; q.tg[pos] = 1.f; q.tb[pos] = 1.f; q.id[pos] = id; q.state[pos] = 0;
         lbuf[id] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[0].n_queue = n;
+    if (threadIdx.x == 0) counts[0].queue[blockIdx.x] = hi - lo;
 }
 
 // ------------------------------------------------------------------ extend --
 __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
-                                                      float4 *lbuf, BounceCounters *counters, int *spill) {
+                                                      uint32_t segcap, float4 *lbuf, BounceCounts *counts, BounceStats *stats, int *spill) {
     __shared__ int s_stack[RT_LDS_STACK * RT_BLOCK];
-    BounceCounters *bc = counters + bounce;
-    const uint32_t n = bc->n_queue;
+    __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE], s_cls[RT_NUM_CLASSES];
+    BounceCounts *bc = counts + bounce;
+    if (threadIdx.x < RT_NUM_CLASSES) s_cls[threadIdx.x] = 0;
+    const uint32_t total = segment_prefix(bc->queue, s_prefix, s_wave);
+    uint32_t lo, hi;
+    block_share(total, lo, hi);
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_queue = total;
+    // the shading kernels of this bounce append to segment blockIdx.x of the shadow queue and of the next queue
+    if (threadIdx.x == 0) { bc->shadow[blockIdx.x] = 0; counts[bounce + 1].queue[blockIdx.x] = 0; }
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     TravStack st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.sp = 0;
-    uint32_t lane = lane_id();
-    while (true) {
-        uint32_t base = wave_fetch(&bc->fetch_extend);
-        if (base >= n) break;
-        uint32_t i = base + lane;
-        bool active = i < n;
+    uint32_t seg = lo < hi ? segment_of(s_prefix, lo) : 0;
+    const uint32_t seg_base = blockIdx.x * segcap;
+    for (uint32_t base = lo; base < hi; base += RT_BLOCK) {
+        uint32_t g = base + threadIdx.x;
+        bool active = g < hi;
         int cls = -1;
+        uint32_t i = 0;
         if (active) {
+            while (g >= s_prefix[seg + 1]) seg++;
+            i = seg * segcap + (g - s_prefix[seg]);
             F3 o = f3(q.ox[i], q.oy[i], q.oz[i]), d = f3(q.dx[i], q.dy[i], q.dz[i]);
             uint32_t state = q.state[i];
             int depth = state & 0xFFFF; bool spec = (state >> 16) & 1;
@@ -213,14 +253,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, RenderParams r
             }
             if (!terminal) cls = sc.materials[sc.slot_material[h.slot]].kind;
         }
-        // append to the queue of the material class (counting-sort style binning, one ballot per class present)
+        // bin the path into the queue of its material class (one ballot per class present in the wave)
         for (int c = 0; c < RT_NUM_CLASSES; ++c) {
             bool mine = (cls == c);
             if (__ballot(mine) == 0) continue;
-            uint32_t pos = wave_append(mine, &bc->cls[c]);
-            if (mine) cls_list[(size_t)c * cap + pos] = i;
+            uint32_t pos = block_append(mine, &s_cls[c]);
+            if (mine) cls_list[(size_t)c * cap + seg_base + pos] = i;
         }
     }
+    __syncthreads();
+    if (threadIdx.x < RT_NUM_CLASSES) bc->cls[threadIdx.x][blockIdx.x] = s_cls[threadIdx.x];
 }
 
 // ------------------------------------------------------------------- shade --
@@ -395,21 +437,26 @@ __device__ __forceinline__ void build_lobe(const DevScene &sc, const DevMaterial
 
 template <int MAT>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, RenderParams rp, int bounce, PathQueue q, PathQueue qn, HitBuf hb, const uint32_t *cls_list,
-                                                     uint32_t cap, ShadowQueue sq, BounceCounters *counters) {
-    BounceCounters *bc = counters + bounce;
-    const uint32_t n = bc->cls[MAT];
+                                                     uint32_t cap, uint32_t segcap, ShadowQueue sq, BounceCounts *counts) {
+    __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE], s_out[2];
+    BounceCounts *bc = counts + bounce;
     const uint32_t *list = cls_list + (size_t)MAT * cap;
-    uint32_t lane = lane_id();
-    while (true) {
-        uint32_t base = wave_fetch(&bc->fetch_cls[MAT]);
-        if (base >= n) break;
-        uint32_t j = base + lane;
-        bool active = j < n;
+    // continue this block's segments where the previous class kernel of this bounce left them
+    if (threadIdx.x == 0) { s_out[0] = bc->shadow[blockIdx.x]; s_out[1] = counts[bounce + 1].queue[blockIdx.x]; }
+    const uint32_t total = segment_prefix(bc->cls[MAT], s_prefix, s_wave);
+    uint32_t lo, hi;
+    block_share(total, lo, hi);
+    uint32_t seg = lo < hi ? segment_of(s_prefix, lo) : 0;
+    const uint32_t seg_base = blockIdx.x * segcap;
+    for (uint32_t base = lo; base < hi; base += RT_BLOCK) {
+        uint32_t j = base + threadIdx.x;
+        bool active = j < hi;
         bool has_shadow = false, has_next = false;
         uint32_t id = 0, nstate = 0;
         F3 so = f3(0, 0, 0), sd = f3(0, 0, 0), sc3 = f3(0, 0, 0), no = f3(0, 0, 0), nd = f3(0, 0, 0), nT = f3(0, 0, 0);
         if (active) {
-            uint32_t i = list[j];
+            while (j >= s_prefix[seg + 1]) seg++;
+            uint32_t i = list[seg * segcap + (j - s_prefix[seg])];
             F3 o = f3(q.ox[i], q.oy[i], q.oz[i]), d = f3(q.dx[i], q.dy[i], q.dz[i]);
             F3 T = f3(q.tr[i], q.tg[i], q.tb[i]);
             id = q.id[i];
@@ -509,41 +556,45 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, RenderParams rp
                 }
             }
         }
-        uint32_t spos = wave_append(has_shadow, &bc->n_shadow);
+        uint32_t spos = seg_base + block_append(has_shadow, &s_out[0]);
         if (has_shadow) {
             sq.id[spos] = id; sq.ox[spos] = so.x; sq.oy[spos] = so.y; sq.oz[spos] = so.z; sq.dx[spos] = sd.x; sq.dy[spos] = sd.y; sq.dz[spos] = sd.z;
             sq.cr[spos] = sc3.x; sq.cg[spos] = sc3.y; sq.cb[spos] = sc3.z;
         }
-        uint32_t npos = wave_append(has_next, &counters[bounce + 1].n_queue);
+        uint32_t npos = seg_base + block_append(has_next, &s_out[1]);
         if (has_next) {
             qn.ox[npos] = no.x; qn.oy[npos] = no.y; qn.oz[npos] = no.z; qn.dx[npos] = nd.x; qn.dy[npos] = nd.y; qn.dz[npos] = nd.z;
             qn.tr[npos] = nT.x; qn.tg[npos] = nT.y; qn.tb[npos] = nT.z; qn.id[npos] = id; qn.state[npos] = nstate;
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) { bc->shadow[blockIdx.x] = s_out[0]; counts[bounce + 1].queue[blockIdx.x] = s_out[1]; }
 }
 
 // ------------------------------------------------------------------ shadow --
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, ShadowQueue sq, float4 *lbuf, BounceCounters *counters, int *spill) {
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, ShadowQueue sq, uint32_t segcap, float4 *lbuf, BounceCounts *counts,
+                                                      BounceStats *stats, int *spill) {
     __shared__ int s_stack[RT_LDS_STACK * RT_BLOCK];
-    BounceCounters *bc = counters + bounce;
-    const uint32_t n = bc->n_shadow;
+    __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE];
+    BounceCounts *bc = counts + bounce;
+    const uint32_t total = segment_prefix(bc->shadow, s_prefix, s_wave);
+    uint32_t lo, hi;
+    block_share(total, lo, hi);
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_shadow = total;
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     TravStack st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.sp = 0;
-    uint32_t lane = lane_id();
-    while (true) {
-        uint32_t base = wave_fetch(&bc->fetch_shadow);
-        if (base >= n) break;
-        uint32_t i = base + lane;
-        if (i < n) {
-            F3 o = f3(sq.ox[i], sq.oy[i], sq.oz[i]), d = f3(sq.dx[i], sq.dy[i], sq.dz[i]);
-            HitRec h; uint32_t c0 = 0, c1 = 0;
-            bool occluded = traverse<true, false>(sc, o, d, 1.f - 0.0001f, st, h, c0, c1);   // tMax = 1 - ShadowEpsilon
-            if (!occluded) {
-                uint32_t id = sq.id[i];
-                float4 L = lbuf[id];
-                L.x += sq.cr[i]; L.y += sq.cg[i]; L.z += sq.cb[i];
-                lbuf[id] = L;
-            }
+    uint32_t seg = lo < hi ? segment_of(s_prefix, lo) : 0;
+    for (uint32_t g = lo + threadIdx.x; g < hi; g += RT_BLOCK) {
+        while (g >= s_prefix[seg + 1]) seg++;
+        uint32_t i = seg * segcap + (g - s_prefix[seg]);
+        F3 o = f3(sq.ox[i], sq.oy[i], sq.oz[i]), d = f3(sq.dx[i], sq.dy[i], sq.dz[i]);
+        HitRec h; uint32_t c0 = 0, c1 = 0;
+        bool occluded = traverse<true, false>(sc, o, d, 1.f - 0.0001f, st, h, c0, c1);   // tMax = 1 - ShadowEpsilon
+        if (!occluded) {
+            uint32_t id = sq.id[i];
+            float4 L = lbuf[id];
+            L.x += sq.cr[i]; L.y += sq.cg[i]; L.z += sq.cb[i];
+            lbuf[id] = L;
         }
     }
 }
@@ -591,7 +642,7 @@ struct rt_scene {
 static rt_ctx *ctx_of(rt_ctx *c) { return c; }
 static rt_ctx *ctx_of(rt_scene *s) { return s ? s->ctx : nullptr; }
 
-static int persistent_grid(rt_ctx *c) { return c->n_cu * 8; }
+static int persistent_grid(rt_ctx *c) { return c->n_cu * 8; }   // batch trace kernels (grid-stride)
 
 namespace {
 // Host-side copies of the reference's float helpers used while precomputing per-triangle frames
@@ -889,10 +940,10 @@ static void bind_queue(PathQueue &q, void *base, size_t cap) {
 
 extern "C++" {
 template <int MAT>
-static void launch_shade(rt_scene *s, int grid, const RenderParams &rp, int bounce, const PathQueue &q, const PathQueue &qn, const HitBuf &hb, uint32_t cap,
-                         const ShadowQueue &sq) {
-    hipLaunchKernelGGL((k_shade<MAT>), dim3(grid), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p, cap, sq,
-                       (BounceCounters *)s->d_counters.p);
+static void launch_shade(rt_scene *s, const RenderParams &rp, int bounce, const PathQueue &q, const PathQueue &qn, const HitBuf &hb, uint32_t cap,
+                         uint32_t segcap, const ShadowQueue &sq) {
+    hipLaunchKernelGGL((k_shade<MAT>), dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p, cap,
+                       segcap, sq, (BounceCounts *)s->d_counters.p);
 }
 }  // extern "C++"
 
@@ -909,7 +960,13 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     int S = o->sample_end - o->sample_begin;
     size_t pool = o->pool_paths > 0 ? (size_t)o->pool_paths : ((size_t)16 << 20);
     int spb = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(S, 1), pool / npix));
-    size_t cap = npix * (size_t)spb;
+    size_t n_pass = npix * (size_t)spb;
+    if (n_pass >= (1ull << 31)) { set_error(ctx, "rt_render: pass too large"); return -1; }
+    // segment capacity: a block's share of the pass, plus room for the rounding of every class kernel's share
+    size_t share = (n_pass + RT_SEG_BLOCKS - 1) / RT_SEG_BLOCKS;
+    share = (share + RT_WAVE - 1) & ~(size_t)(RT_WAVE - 1);
+    size_t segcap = share + (size_t)RT_WAVE * RT_NUM_CLASSES;
+    size_t cap = segcap * RT_SEG_BLOCKS;
     if (cap >= (1ull << 31)) { set_error(ctx, "rt_render: pass too large"); return -1; }
     if (cap > this_->ws_cap) {
         HIP_OK(this_->d_q[0].alloc(11 * cap * 4)); HIP_OK(this_->d_q[1].alloc(11 * cap * 4));
@@ -918,7 +975,8 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
         this_->ws_cap = cap;
     }
     size_t n_bounce = (size_t)o->max_depth + 2;
-    HIP_OK(this_->d_counters.ensure(n_bounce * sizeof(BounceCounters)));
+    size_t counts_bytes = n_bounce * sizeof(BounceCounts), stats_bytes = n_bounce * sizeof(BounceStats);
+    HIP_OK(this_->d_counters.ensure(counts_bytes + stats_bytes));
     bool fresh = this_->sum_pixels != npix || !(o->flags & RT_RENDER_ACCUMULATE);
     if (this_->sum_pixels != npix) { HIP_OK(this_->d_sum.alloc(npix * 3 * 4)); this_->sum_pixels = npix; }
     if (fresh) HIP_OK(hipMemsetAsync(this_->d_sum.p, 0, npix * 3 * 4, ctx->stream));
@@ -928,9 +986,11 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     HitBuf hb; { float *f = (float *)this_->d_hits.p; hb.slot = (int *)f; hb.t = f + wcap; hb.b0 = f + 2 * wcap; hb.b1 = f + 3 * wcap; hb.b2 = f + 4 * wcap; }
     ShadowQueue sq; { float *f = (float *)this_->d_shadow.p; sq.id = (uint32_t *)f; sq.ox = f + wcap; sq.oy = f + 2 * wcap; sq.oz = f + 3 * wcap; sq.dx = f + 4 * wcap;
                       sq.dy = f + 5 * wcap; sq.dz = f + 6 * wcap; sq.cr = f + 7 * wcap; sq.cg = f + 8 * wcap; sq.cb = f + 9 * wcap; }
-    BounceCounters *counters = (BounceCounters *)this_->d_counters.p;
+    BounceCounts *counts = (BounceCounts *)this_->d_counters.p;
+    BounceStats *bstats = (BounceStats *)((char *)this_->d_counters.p + counts_bytes);
     float4 *lbuf = (float4 *)this_->d_lbuf.p;
     int grid = persistent_grid(ctx);
+    if (RT_SEG_BLOCKS * RT_BLOCK > grid * RT_BLOCK) { set_error(ctx, "rt_render: spill area smaller than the wavefront grid"); return -1; }
 
     RenderParams rp; memset(&rp, 0, sizeof(rp));
     memcpy(rp.r2c, cam->raster_to_camera, 64); memcpy(rp.c2w, cam->camera_to_world, 64);
@@ -940,35 +1000,36 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     HIP_OK(hipEventRecord(e0, ctx->stream));
-    std::vector<BounceCounters> hc(n_bounce);
+    std::vector<BounceStats> hs(n_bounce);
+    const uint32_t ucap = (uint32_t)wcap, useg = (uint32_t)segcap;
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
         int cur = std::min(spb, o->sample_end - s0);
         rp.spb = cur; rp.sample0 = s0; rp.n_paths = (uint32_t)(npix * (size_t)cur);
-        HIP_OK(hipMemsetAsync(counters, 0, n_bounce * sizeof(BounceCounters), ctx->stream));
-        int rg = (int)std::min<size_t>(((size_t)rp.n_paths + RT_BLOCK - 1) / RT_BLOCK, (size_t)grid * 4);
-        hipLaunchKernelGGL(k_raygen, dim3(rg), dim3(RT_BLOCK), 0, ctx->stream, rp, q[0], lbuf, counters);
+        HIP_OK(hipMemsetAsync(bstats, 0, stats_bytes, ctx->stream));
+        hipLaunchKernelGGL(k_raygen, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, rp, q[0], useg, lbuf, counts);
         int cq = 0;
         for (int b = 0; b <= o->max_depth; ++b) {
-            hipLaunchKernelGGL(k_extend, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p, (uint32_t)wcap, lbuf,
-                               counters, (int *)this_->d_spill.p);
+            hipLaunchKernelGGL(k_extend, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p, ucap, useg,
+                               lbuf, counts, bstats, (int *)this_->d_spill.p);
             if (b < o->max_depth) {
-                if (this_->classes[RT_MAT_MATTE]) launch_shade<RT_MAT_MATTE>(this_, grid, rp, b, q[cq], q[cq ^ 1], hb, (uint32_t)wcap, sq);
-                if (this_->classes[RT_MAT_MIRROR]) launch_shade<RT_MAT_MIRROR>(this_, grid, rp, b, q[cq], q[cq ^ 1], hb, (uint32_t)wcap, sq);
-                if (this_->classes[RT_MAT_GLASS]) launch_shade<RT_MAT_GLASS>(this_, grid, rp, b, q[cq], q[cq ^ 1], hb, (uint32_t)wcap, sq);
-                if (this_->classes[RT_MAT_METAL]) launch_shade<RT_MAT_METAL>(this_, grid, rp, b, q[cq], q[cq ^ 1], hb, (uint32_t)wcap, sq);
-                if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, grid, rp, b, q[cq], q[cq ^ 1], hb, (uint32_t)wcap, sq);
+                if (this_->classes[RT_MAT_MATTE]) launch_shade<RT_MAT_MATTE>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
+                if (this_->classes[RT_MAT_MIRROR]) launch_shade<RT_MAT_MIRROR>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
+                if (this_->classes[RT_MAT_GLASS]) launch_shade<RT_MAT_GLASS>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
+                if (this_->classes[RT_MAT_METAL]) launch_shade<RT_MAT_METAL>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
+                if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->dev.n_lights > 0)
-                    hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, lbuf, counters, (int *)this_->d_spill.p);
+                    hipLaunchKernelGGL(k_shadow, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
+                                       (int *)this_->d_spill.p);
             }
             cq ^= 1;
         }
         int ag = (int)std::min<size_t>((npix + RT_BLOCK - 1) / RT_BLOCK, (size_t)grid * 4);
         hipLaunchKernelGGL(k_accumulate, dim3(ag), dim3(RT_BLOCK), 0, ctx->stream, (const float4 *)lbuf, cur, (uint32_t)npix, (float *)this_->d_sum.p);
         HIP_OK(hipGetLastError());
-        HIP_OK(hipMemcpyAsync(hc.data(), counters, n_bounce * sizeof(BounceCounters), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_OK(hipMemcpyAsync(hs.data(), bstats, stats_bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIP_OK(hipStreamSynchronize(ctx->stream));
         st.samples += rp.n_paths;
-        for (size_t b = 0; b < n_bounce; ++b) { st.rays_closest += hc[b].n_queue; st.rays_shadow += hc[b].n_shadow; if (hc[b].n_queue) st.iterations++; }
+        for (size_t b = 0; b < n_bounce; ++b) { st.rays_closest += hs[b].n_queue; st.rays_shadow += hs[b].n_shadow; if (hs[b].n_queue) st.iterations++; }
     }
     HIP_OK(hipEventRecord(e1, ctx->stream));
     HIP_OK(hipEventSynchronize(e1));
