@@ -10,7 +10,7 @@
 
 #define RT_WAVE 64
 #define RT_BLOCK 256
-#define RT_LDS_STACK 24        // traversal stack entries kept in LDS per lane
+#define RT_LDS_STACK 16        // traversal stack entries kept in LDS per lane
 #define RT_MAX_STACK 64        // the reference's nodesToVisit[64] (bvh.cpp:253)
 
 #define RT_PI 3.14159265358979323846f
@@ -225,10 +225,27 @@ struct TravStack {
     }
 };
 
+// Where traversal reads nodes and leaf slots from: HBM (through L1/L2), or a copy of a small scene in LDS.
+struct GlobalFetch {
+    const float4 *nodes, *slots;
+    __device__ __forceinline__ float4 node(int i) const { return nodes[i]; }
+    __device__ __forceinline__ float4 slot(int i) const { return slots[i]; }
+};
+struct LdsFetch {
+    const float4 *nodes, *slots;   // point into __shared__ arrays (address space resolved after inlining)
+    __device__ __forceinline__ float4 node(int i) const { return nodes[i]; }
+    __device__ __forceinline__ float4 slot(int i) const { return slots[i]; }
+};
+#define RT_LDS_SCENE_NODES 128
+#define RT_LDS_SCENE_SLOTS 64
+
 // BVHAccel::Intersect (bvh.cpp:247-282) when ANY == false, BVHAccel::IntersectP (bvh.cpp:284-320) when ANY == true.
-// COUNT adds the number of slab tests / primitive tests to nNodes / nTests.
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool traverse(const DevScene &sc, F3 o, F3 d, float rayTMax, TravStack &st, HitRec &hit, uint32_t &nNodes, uint32_t &nTests) {
+// The visit order, the slab tests and the primitive tests are the reference's; only the control flow is arranged for
+// a 64-wide wave: an inner loop walks interior nodes until the lane reaches a leaf (or runs out of nodes), then the
+// lanes that hold a leaf test its primitives together.  COUNT adds the number of slab / primitive tests to nNodes / nTests.
+template <bool ANY, bool COUNT, class Fetch>
+__device__ __forceinline__ bool traverse(const DevScene &sc, const Fetch &fetch, F3 o, F3 d, float rayTMax, TravStack &st, HitRec &hit, uint32_t &nNodes,
+                                         uint32_t &nTests) {
     hit.slot = -1; hit.t = rayTMax; hit.b0 = hit.b1 = hit.b2 = 0.f;
     if (sc.n_nodes == 0) return false;
     F3 invDir = f3(1.f / d.x, 1.f / d.y, 1.f / d.z);
@@ -236,43 +253,45 @@ __device__ __forceinline__ bool traverse(const DevScene &sc, F3 o, F3 d, float r
     bool found = false;
     int cur = 0;
     st.sp = 0;
-    while (true) {
-        float4 n0 = sc.nodes[2 * cur], n1 = sc.nodes[2 * cur + 1];
-        if (COUNT) nNodes++;
-        bool descend = false;
-        if (slab_test(n0, n1, o, invDir, negx, negy, negz, rayTMax)) {
-            int offset = __float_as_int(n1.z);
-            uint32_t meta = __float_as_uint(n1.w);
-            int nprim = meta & 0xFFFF, axis = (meta >> 16) & 0xFF;
-            if (nprim > 0) {
-                for (int i = 0; i < nprim; ++i) {
-                    int slot = offset + i;
-                    float4 r0 = sc.slots[3 * slot], r1 = sc.slots[3 * slot + 1], r2 = sc.slots[3 * slot + 2];
-                    uint32_t flags = __float_as_uint(r2.y);
-                    if (COUNT) nTests++;
-                    float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-                    bool ok;
-                    if (flags & RT_SLOT_SPHERE) ok = sphere_test(sc.spheres + 32 * (size_t)__float_as_int(r2.w), o, d, rayTMax, t);
-                    else {
-                        ok = triangle_test(f3(r0.x, r0.y, r0.z), f3(r0.w, r1.x, r1.y), f3(r1.z, r1.w, r2.x), o, d, rayTMax, t, b0, b1, b2);
-                        if (!ANY && (flags & RT_SLOT_REJECT_CLOSEST)) ok = false;
-                    }
-                    if (ok) {
-                        if (ANY) return true;
-                        found = true; rayTMax = t;                       // primitive.cpp:39
-                        hit.slot = slot; hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2;
-                    }
-                }
-            } else {
-                descend = true;
+    while (cur >= 0) {
+        int leafFirst = 0, leafCount = 0;
+        while (true) {   // interior walk
+            float4 n0 = fetch.node(2 * cur), n1 = fetch.node(2 * cur + 1);
+            if (COUNT) nNodes++;
+            if (slab_test(n0, n1, o, invDir, negx, negy, negz, rayTMax)) {
+                int offset = __float_as_int(n1.z);
+                uint32_t meta = __float_as_uint(n1.w);
+                int nprim = meta & 0xFFFF, axis = (meta >> 16) & 0xFF;
+                if (nprim > 0) { leafFirst = offset; leafCount = nprim; break; }
                 int neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
                 if (neg) { st.push(cur + 1); cur = offset; }
                 else { st.push(offset); cur = cur + 1; }
+            } else {
+                if (st.sp == 0) { cur = -1; break; }
+                cur = st.pop();
             }
         }
-        if (!descend) {
-            if (st.sp == 0) break;
-            cur = st.pop();
+        for (int i = 0; i < leafCount; ++i) {
+            int slot = leafFirst + i;
+            float4 r0 = fetch.slot(3 * slot), r1 = fetch.slot(3 * slot + 1), r2 = fetch.slot(3 * slot + 2);
+            uint32_t flags = __float_as_uint(r2.y);
+            if (COUNT) nTests++;
+            float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+            bool ok;
+            if (flags & RT_SLOT_SPHERE) ok = sphere_test(sc.spheres + 32 * (size_t)__float_as_int(r2.w), o, d, rayTMax, t);
+            else {
+                ok = triangle_test(f3(r0.x, r0.y, r0.z), f3(r0.w, r1.x, r1.y), f3(r1.z, r1.w, r2.x), o, d, rayTMax, t, b0, b1, b2);
+                if (!ANY && (flags & RT_SLOT_REJECT_CLOSEST)) ok = false;
+            }
+            if (ok) {
+                if (ANY) return true;
+                found = true; rayTMax = t;                       // primitive.cpp:39
+                hit.slot = slot; hit.t = t; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2;
+            }
+        }
+        if (leafCount > 0) {
+            if (st.sp == 0) cur = -1;
+            else cur = st.pop();
         }
     }
     return found;

@@ -32,7 +32,7 @@
     } while (0)
 
 #define RT_NUM_CLASSES 6
-#define RT_SEG_BLOCKS 1024      // persistent grid of every wavefront kernel == number of queue segments
+#define RT_SEG_BLOCKS 1280      // persistent grid of every wavefront kernel == number of queue segments
 #define RT_SEG_PER_THREAD (RT_SEG_BLOCKS / RT_BLOCK)
 
 // Queues are segmented: block b of a producer kernel appends only to segment b (positions
@@ -128,7 +128,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_batch(DevScene sc, size_t n,
         if (aos) { o = f3(rays[7 * i], rays[7 * i + 1], rays[7 * i + 2]); d = f3(rays[7 * i + 3], rays[7 * i + 4], rays[7 * i + 5]); tmax = rays[7 * i + 6]; }
         else { o = f3(rays[i], rays[n + i], rays[2 * n + i]); d = f3(rays[3 * n + i], rays[4 * n + i], rays[5 * n + i]); tmax = rays[6 * n + i]; }
         HitRec h;
-        bool found = traverse<ANY, COUNT>(sc, o, d, tmax, st, h, nNodes, nTests);
+        GlobalFetch gf; gf.nodes = sc.nodes; gf.slots = sc.slots;
+        bool found = traverse<ANY, COUNT>(sc, gf, o, d, tmax, st, h, nNodes, nTests);
         if (ANY) out_any[i] = found ? 1 : 0;
         else {
             int prim = -1; float b1 = h.b1, b2 = h.b2;
@@ -196,9 +197,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderParams rp, PathQueue 
 }
 
 // ------------------------------------------------------------------ extend --
+// Copy a small scene (nodes + leaf slots) into LDS; all threads of the block take part.
+__device__ __forceinline__ void stage_scene_lds(const DevScene &sc, float4 *s_nodes, float4 *s_slots) {
+    for (int i = threadIdx.x; i < 2 * sc.n_nodes; i += RT_BLOCK) s_nodes[i] = sc.nodes[i];
+    for (int i = threadIdx.x; i < 3 * sc.n_slots; i += RT_BLOCK) s_slots[i] = sc.slots[i];
+}
+
+template <bool LDS_SCENE>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
                                                       uint32_t segcap, float4 *lbuf, BounceCounts *counts, BounceStats *stats, int *spill) {
     __shared__ int s_stack[RT_LDS_STACK * RT_BLOCK];
+    __shared__ float4 s_nodes[LDS_SCENE ? 2 * RT_LDS_SCENE_NODES : 1], s_slots[LDS_SCENE ? 3 * RT_LDS_SCENE_SLOTS : 1];
+    if (LDS_SCENE) stage_scene_lds(sc, s_nodes, s_slots);
     __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE], s_cls[RT_NUM_CLASSES];
     BounceCounts *bc = counts + bounce;
     if (threadIdx.x < RT_NUM_CLASSES) s_cls[threadIdx.x] = 0;
@@ -224,7 +234,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, RenderParams r
             uint32_t state = q.state[i];
             int depth = state & 0xFFFF; bool spec = (state >> 16) & 1;
             HitRec h; uint32_t c0 = 0, c1 = 0;
-            bool found = traverse<false, false>(sc, o, d, RT_INF, st, h, c0, c1);
+            bool found;
+            if (LDS_SCENE) { LdsFetch lf; lf.nodes = s_nodes; lf.slots = s_slots; found = traverse<false, false>(sc, lf, o, d, RT_INF, st, h, c0, c1); }
+            else { GlobalFetch gf; gf.nodes = sc.nodes; gf.slots = sc.slots; found = traverse<false, false>(sc, gf, o, d, RT_INF, st, h, c0, c1); }
             hb.slot[i] = h.slot; hb.t[i] = h.t; hb.b0[i] = h.b0; hb.b1[i] = h.b1; hb.b2[i] = h.b2;
             // integrator.cpp:242-257
             F3 add = f3(0.f, 0.f, 0.f); bool terminal = false;
@@ -572,9 +584,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, RenderParams rp
 }
 
 // ------------------------------------------------------------------ shadow --
+template <bool LDS_SCENE>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, ShadowQueue sq, uint32_t segcap, float4 *lbuf, BounceCounts *counts,
                                                       BounceStats *stats, int *spill) {
     __shared__ int s_stack[RT_LDS_STACK * RT_BLOCK];
+    __shared__ float4 s_nodes[LDS_SCENE ? 2 * RT_LDS_SCENE_NODES : 1], s_slots[LDS_SCENE ? 3 * RT_LDS_SCENE_SLOTS : 1];
+    if (LDS_SCENE) stage_scene_lds(sc, s_nodes, s_slots);
     __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE];
     BounceCounts *bc = counts + bounce;
     const uint32_t total = segment_prefix(bc->shadow, s_prefix, s_wave);
@@ -589,7 +604,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, Sh
         uint32_t i = seg * segcap + (g - s_prefix[seg]);
         F3 o = f3(sq.ox[i], sq.oy[i], sq.oz[i]), d = f3(sq.dx[i], sq.dy[i], sq.dz[i]);
         HitRec h; uint32_t c0 = 0, c1 = 0;
-        bool occluded = traverse<true, false>(sc, o, d, 1.f - 0.0001f, st, h, c0, c1);   // tMax = 1 - ShadowEpsilon
+        bool occluded;   // tMax = 1 - ShadowEpsilon
+        if (LDS_SCENE) { LdsFetch lf; lf.nodes = s_nodes; lf.slots = s_slots; occluded = traverse<true, false>(sc, lf, o, d, 1.f - 0.0001f, st, h, c0, c1); }
+        else { GlobalFetch gf; gf.nodes = sc.nodes; gf.slots = sc.slots; occluded = traverse<true, false>(sc, gf, o, d, 1.f - 0.0001f, st, h, c0, c1); }
         if (!occluded) {
             uint32_t id = sq.id[i];
             float4 L = lbuf[id];
@@ -1002,6 +1019,8 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     HIP_OK(hipEventRecord(e0, ctx->stream));
     std::vector<BounceStats> hs(n_bounce);
     const uint32_t ucap = (uint32_t)wcap, useg = (uint32_t)segcap;
+    // scenes small enough are traversed out of an LDS copy (no spheres: their records stay in global memory)
+    const bool lds_scene = this_->dev.n_nodes <= RT_LDS_SCENE_NODES && this_->dev.n_slots <= RT_LDS_SCENE_SLOTS;
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
         int cur = std::min(spb, o->sample_end - s0);
         rp.spb = cur; rp.sample0 = s0; rp.n_paths = (uint32_t)(npix * (size_t)cur);
@@ -1009,17 +1028,26 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
         hipLaunchKernelGGL(k_raygen, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, rp, q[0], useg, lbuf, counts);
         int cq = 0;
         for (int b = 0; b <= o->max_depth; ++b) {
-            hipLaunchKernelGGL(k_extend, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p, ucap, useg,
-                               lbuf, counts, bstats, (int *)this_->d_spill.p);
+            if (lds_scene)
+                hipLaunchKernelGGL(k_extend<true>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p, ucap,
+                                   useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
+            else
+                hipLaunchKernelGGL(k_extend<false>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p, ucap,
+                                   useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
             if (b < o->max_depth) {
                 if (this_->classes[RT_MAT_MATTE]) launch_shade<RT_MAT_MATTE>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->classes[RT_MAT_MIRROR]) launch_shade<RT_MAT_MIRROR>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->classes[RT_MAT_GLASS]) launch_shade<RT_MAT_GLASS>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->classes[RT_MAT_METAL]) launch_shade<RT_MAT_METAL>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
-                if (this_->dev.n_lights > 0)
-                    hipLaunchKernelGGL(k_shadow, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
-                                       (int *)this_->d_spill.p);
+                if (this_->dev.n_lights > 0) {
+                    if (lds_scene)
+                        hipLaunchKernelGGL(k_shadow<true>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
+                                           (int *)this_->d_spill.p);
+                    else
+                        hipLaunchKernelGGL(k_shadow<false>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
+                                           (int *)this_->d_spill.p);
+                }
             }
             cq ^= 1;
         }
