@@ -206,24 +206,32 @@ __device__ __forceinline__ bool sphere_test(const float *sp, F3 o, F3 d, float r
 
 struct HitRec { int slot; float t, b0, b1, b2; };
 
-// Per-lane traversal stack: the first RT_LDS_STACK entries live in LDS ([entry][thread], conflict-free),
-// deeper ones in a global spill area ([entry][global thread]).
-struct TravStack {
-    int *lds;            // &shared[0][threadIdx.x]
+// Per-lane traversal stack.  The newest N entries live in an LDS ring ([entry][thread]: bank = thread, conflict-free);
+// when the ring is full the oldest entry moves to a global spill area ([entry][global thread]) and comes back when the
+// stack shrinks down to it, so the hot top of the stack never leaves LDS however deep the tree is.  Logical depth is
+// capped at RT_MAX_STACK like the reference's nodesToVisit[64] (bvh.cpp:253).
+template <int N>
+struct TravStackT {
+    int *lds;            // &shared[0][threadIdx.x], stride RT_BLOCK
     int *spill;          // &spill[0][global thread]
     size_t spill_stride;
-    int sp;
+    int sp, lo;          // entries [lo, sp) are in the ring
+    __device__ __forceinline__ void reset() { sp = 0; lo = 0; }
     __device__ __forceinline__ void push(int v) {
-        if (sp < RT_LDS_STACK) lds[sp * RT_BLOCK] = v;
-        else if (sp < RT_MAX_STACK) spill[(size_t)(sp - RT_LDS_STACK) * spill_stride] = v;
+        if (sp - lo == N) {
+            if (lo < RT_MAX_STACK) spill[(size_t)lo * spill_stride] = lds[(lo & (N - 1)) * RT_BLOCK];
+            lo++;
+        }
+        lds[(sp & (N - 1)) * RT_BLOCK] = v;
         sp++;
     }
     __device__ __forceinline__ int pop() {
         sp--;
-        if (sp < RT_LDS_STACK) return lds[sp * RT_BLOCK];
-        return sp < RT_MAX_STACK ? spill[(size_t)(sp - RT_LDS_STACK) * spill_stride] : 0;
+        if (sp < lo) { lo = sp; return sp < RT_MAX_STACK ? spill[(size_t)sp * spill_stride] : 0; }
+        return lds[(sp & (N - 1)) * RT_BLOCK];
     }
 };
+typedef TravStackT<RT_LDS_STACK> TravStack;
 
 // Where traversal reads nodes and leaf slots from: HBM (through L1/L2), or a copy of a small scene in LDS.
 struct GlobalFetch {
@@ -243,8 +251,8 @@ struct LdsFetch {
 // The visit order, the slab tests and the primitive tests are the reference's; only the control flow is arranged for
 // a 64-wide wave: an inner loop walks interior nodes until the lane reaches a leaf (or runs out of nodes), then the
 // lanes that hold a leaf test its primitives together.  COUNT adds the number of slab / primitive tests to nNodes / nTests.
-template <bool ANY, bool COUNT, class Fetch>
-__device__ __forceinline__ bool traverse(const DevScene &sc, const Fetch &fetch, F3 o, F3 d, float rayTMax, TravStack &st, HitRec &hit, uint32_t &nNodes,
+template <bool ANY, bool COUNT, class Fetch, class Stack>
+__device__ __forceinline__ bool traverse(const DevScene &sc, const Fetch &fetch, F3 o, F3 d, float rayTMax, Stack &st, HitRec &hit, uint32_t &nNodes,
                                          uint32_t &nTests) {
     hit.slot = -1; hit.t = rayTMax; hit.b0 = hit.b1 = hit.b2 = 0.f;
     if (sc.n_nodes == 0) return false;
@@ -252,7 +260,7 @@ __device__ __forceinline__ bool traverse(const DevScene &sc, const Fetch &fetch,
     int negx = invDir.x < 0, negy = invDir.y < 0, negz = invDir.z < 0;
     bool found = false;
     int cur = 0;
-    st.sp = 0;
+    st.reset();
     while (cur >= 0) {
         int leafFirst = 0, leafCount = 0;
         while (true) {   // interior walk

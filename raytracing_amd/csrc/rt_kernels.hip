@@ -32,6 +32,7 @@
     } while (0)
 
 #define RT_NUM_CLASSES 6
+#define RT_BATCH_STACK 32       // LDS ring depth of the batch trace kernels (deep trees)
 #define RT_SEG_BLOCKS 1280      // persistent grid of every wavefront kernel == number of queue segments
 #define RT_SEG_PER_THREAD (RT_SEG_BLOCKS / RT_BLOCK)
 
@@ -119,9 +120,9 @@ __device__ __forceinline__ uint32_t block_append(bool want, uint32_t *s_counter)
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_batch(DevScene sc, size_t n, const float *__restrict__ rays, int aos, int *out_prim, float *out_t,
                                                            float *out_b1, float *out_b2, uint8_t *out_any, int *spill, unsigned long long *work) {
-    __shared__ int s_stack[RT_LDS_STACK * RT_BLOCK];
+    __shared__ int s_stack[RT_BATCH_STACK * RT_BLOCK];
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    TravStack st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.sp = 0;
+    TravStackT<RT_BATCH_STACK> st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.reset();
     uint32_t nNodes = 0, nTests = 0;
     for (size_t i = gtid; i < n; i += nthreads) {
         F3 o, d; float tmax;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, RenderParams r
     // the shading kernels of this bounce append to segment blockIdx.x of the shadow queue and of the next queue
     if (threadIdx.x == 0) { bc->shadow[blockIdx.x] = 0; counts[bounce + 1].queue[blockIdx.x] = 0; }
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    TravStack st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.sp = 0;
+    TravStack st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.reset();
     uint32_t seg = lo < hi ? segment_of(s_prefix, lo) : 0;
     const uint32_t seg_base = blockIdx.x * segcap;
     for (uint32_t base = lo; base < hi; base += RT_BLOCK) {
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, Sh
     block_share(total, lo, hi);
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_shadow = total;
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    TravStack st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.sp = 0;
+    TravStack st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.reset();
     uint32_t seg = lo < hi ? segment_of(s_prefix, lo) : 0;
     for (uint32_t g = lo + threadIdx.x; g < hi; g += RT_BLOCK) {
         while (g >= s_prefix[seg + 1]) seg++;
@@ -847,7 +848,7 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     HIP_OK(up(sc->d_mats, mats.data(), mats.size() * sizeof(DevMaterial)));
     HIP_OK(up(sc->d_tex, tex.data(), tex.size() * sizeof(DevTexture)));
     HIP_OK(up(sc->d_lights, lights.data(), lights.size() * sizeof(DevLight)));
-    size_t spill_ints = (size_t)persistent_grid(ctx) * RT_BLOCK * (RT_MAX_STACK - RT_LDS_STACK);
+    size_t spill_ints = (size_t)persistent_grid(ctx) * RT_BLOCK * RT_MAX_STACK;
     HIP_OK(sc->d_spill.alloc(spill_ints * 4));
     DevScene &D = sc->dev;
     D.nodes = (const float4 *)sc->d_nodes.p; D.slots = (const float4 *)sc->d_slots.p; D.frames = (const float4 *)sc->d_frames.p;
