@@ -52,7 +52,7 @@ def traversal_roofline(ctx, n_tris, n_rays, repeats):
     bytes_per_launch = 32.0 * nodes + 36.0 * tests + 48.0 * n_rays
     achieved = bytes_per_launch / st.seconds / 1e9
     prim = hits[0].view(torch.int32)
-    out = {"bound": "hbm", "kernel": "k_trace_batch<closest>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    out = {"bound": "hbm", "kernel": "k_trace_pairs<closest>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
            "workload": "%d-triangle soup, %d incoherent rays" % (n_tris, n_rays),
            "bytes_per_ray": round(bytes_per_launch / n_rays, 1), "nodes_per_ray": round(nodes / n_rays, 2), "tris_per_ray": round(tests / n_rays, 2),

@@ -49,7 +49,11 @@ struct DevScene {
     const DevMaterial *materials;
     const DevTexture *textures;
     const DevLight *lights;
-    int n_nodes, n_slots, n_lights, pad;
+    const float4 *pairs;      // 4 x float4 per INTERIOR node: left box | right box | left info, right info, split axis, -  (rt_traverse2.h)
+    int n_nodes, n_slots, n_lights, n_pairs;
+    float root_box[6];        // bounds of node 0
+    uint32_t root_info;       // pair index of the root, or a leaf code when the tree is a single leaf
+    uint32_t pad;
 };
 
 struct F3 { float x, y, z; };

@@ -24,6 +24,7 @@
 
 #include "rt_amd.h"
 #include "rt_device.h"
+#include "rt_traverse2.h"
 
 #define HIP_OK(expr)                                                                                        \
     do {                                                                                                    \
@@ -149,6 +150,79 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_batch(DevScene sc, size_t n,
             }
             out_prim[i] = prim; out_t[i] = h.t;
             if (out_b1) { out_b1[i] = b1; out_b2[i] = b2; }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&work[0], (unsigned long long)nNodes);
+        atomicAdd(&work[1], (unsigned long long)nTests);
+    }
+}
+
+// Batch trace over pair nodes with persistent lanes (rt_traverse2.h).  Each wave owns a contiguous range of rays.
+#define RT_LEAF_MIN_LANES 12
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_pairs(DevScene sc, size_t n, const float *__restrict__ rays, int aos, int *out_prim, float *out_t,
+                                                           float *out_b1, float *out_b2, uint8_t *out_any, int *spill, unsigned long long *work) {
+    __shared__ int s_si[RT_PAIR_STACK * RT_BLOCK];
+    __shared__ float s_st[RT_PAIR_STACK * RT_BLOCK];
+    size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    PairStack st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
+    st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)RT_MAX_STACK * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
+    size_t nwaves = nthreads / RT_WAVE, gw = gtid / RT_WAVE;
+    size_t per = ((n + nwaves - 1) / nwaves + RT_WAVE - 1) & ~(size_t)(RT_WAVE - 1);
+    size_t w_lo = gw * per < n ? gw * per : n, w_hi = w_lo + per < n ? w_lo + per : n;
+    size_t next = w_lo;
+    long long ri = -1;
+    bool pending = false;
+    F3 po = f3(0, 0, 0), pd = f3(0, 0, 1); float ptmax = 0.f;
+    LaneTrav L; L.mode = RT_LANE_DONE; L.found = false; L.hitSlot = -1; L.tmax = 0.f; L.b0 = L.b1 = L.b2 = 0.f;
+    uint32_t nNodes = 0, nTests = 0;
+    while (true) {
+        if (pending) { lane_begin<COUNT>(sc, L, st, po, pd, ptmax, nNodes); pending = false; }
+        if (ri >= 0 && L.mode == RT_LANE_DONE) {   // retire
+            size_t i = (size_t)ri;
+            if (ANY) out_any[i] = L.found ? 1 : 0;
+            else {
+                int prim = -1; float b1 = L.b1, b2 = L.b2;
+                if (L.found) {
+                    float4 r2 = sc.slots[3 * (size_t)L.hitSlot + 2];
+                    prim = __float_as_int(r2.z);
+                    if (__float_as_uint(r2.y) & RT_SLOT_SPHERE) {   // (u, v) of the hit, sphere.cpp:51-58
+                        const float *sp = sc.spheres + 32 * (size_t)__float_as_int(r2.w);
+                        F3 oo = xf_point(sp + 4, L.o), dd = xf_vector(sp + 4, L.d);
+                        F3 ph = oo + L.tmax * dd;
+                        float phi = atan2f(ph.y, ph.x);
+                        if (phi < 0) phi += 2 * RT_PI;
+                        b1 = phi / (2 * RT_PI);
+                        b2 = acosf(clampf(ph.z / sp[0], -1.f, 1.f)) / RT_PI;
+                    }
+                }
+                out_prim[i] = prim; out_t[i] = L.tmax;
+                if (out_b1) { out_b1[i] = b1; out_b2[i] = b2; }
+            }
+            ri = -1;
+        }
+        bool idle = ri < 0;
+        uint64_t im = __ballot(idle);
+        if (im != 0 && next < w_hi) {
+            uint32_t rank = prefix_in_mask(im);
+            size_t cand = next + rank;
+            if (idle && cand < w_hi) {
+                ri = (long long)cand;
+                size_t i = cand;
+                if (aos) { po = f3(rays[7 * i], rays[7 * i + 1], rays[7 * i + 2]); pd = f3(rays[7 * i + 3], rays[7 * i + 4], rays[7 * i + 5]); ptmax = rays[7 * i + 6]; }
+                else { po = f3(rays[i], rays[n + i], rays[2 * n + i]); pd = f3(rays[3 * n + i], rays[4 * n + i], rays[5 * n + i]); ptmax = rays[6 * n + i]; }
+                pending = true;
+            }
+            next += __popcll(im);
+        }
+        if (__ballot(ri >= 0) == 0) break;
+        bool act = ri >= 0 && !pending;
+        if (act && L.mode == RT_LANE_WALK) lane_walk<COUNT>(sc, L, st, nNodes);
+        bool leaf = act && L.mode == RT_LANE_LEAF;
+        uint64_t lm = __ballot(leaf), wm = __ballot(act && L.mode == RT_LANE_WALK);
+        if (lm != 0 && (__popcll(lm) >= RT_LEAF_MIN_LANES || wm == 0)) {
+            if (leaf) lane_leaf<ANY, COUNT>(sc, L, st, nTests);
         }
     }
     if (COUNT) {
@@ -649,7 +723,7 @@ struct rt_scene {
     std::vector<rt_bvh_node> nodes; std::vector<int32_t> order;
     int n_prims = 0;
     bool classes[RT_NUM_CLASSES] = {false, false, false, false, false, false};
-    DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_spill;
+    DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_spill, d_pairs;
     std::vector<DevBuf *> d_texels;
     // render workspace
     DevBuf d_q[2], d_hits, d_cls, d_shadow, d_lbuf, d_counters, d_sum, d_trace_io, d_work;
@@ -848,13 +922,38 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     HIP_OK(up(sc->d_mats, mats.data(), mats.size() * sizeof(DevMaterial)));
     HIP_OK(up(sc->d_tex, tex.data(), tex.size() * sizeof(DevTexture)));
     HIP_OK(up(sc->d_lights, lights.data(), lights.size() * sizeof(DevLight)));
-    size_t spill_ints = (size_t)persistent_grid(ctx) * RT_BLOCK * RT_MAX_STACK;
+    // pair nodes: one 64-byte record per interior node with both children's boxes
+    std::vector<int32_t> pairIndex(nn, -1);
+    int n_pairs = 0;
+    for (int i = 0; i < nn; ++i) if (sc->nodes[i].nprim == 0) pairIndex[i] = n_pairs++;
+    auto childInfo = [&](int c) -> uint32_t {
+        const rt_bvh_node &nd = sc->nodes[c];
+        if (nd.nprim == 0) return (uint32_t)pairIndex[c];
+        if (nd.nprim == 1) return RT_PAIR_LEAF | (uint32_t)nd.offset;
+        return RT_PAIR_LEAF_MULTI | (uint32_t)c;
+    };
+    if (nn >= (1 << 30)) { set_error(ctx, "rt_scene_create: tree too large"); return -1; }
+    std::vector<float> pairs(16 * (size_t)std::max(1, n_pairs), 0.f);
+    for (int i = 0; i < nn; ++i) {
+        if (sc->nodes[i].nprim != 0) continue;
+        float *P = &pairs[16 * (size_t)pairIndex[i]];
+        int l = i + 1, r = sc->nodes[i].offset;
+        memcpy(P, sc->nodes[l].bmin, 12); memcpy(P + 3, sc->nodes[l].bmax, 12);
+        memcpy(P + 6, sc->nodes[r].bmin, 12); memcpy(P + 9, sc->nodes[r].bmax, 12);
+        uint32_t il = childInfo(l), ir = childInfo(r); int32_t axis = sc->nodes[i].axis;
+        memcpy(P + 12, &il, 4); memcpy(P + 13, &ir, 4); memcpy(P + 14, &axis, 4);
+    }
+    HIP_OK(up(sc->d_pairs, pairs.data(), pairs.size() * 4));
+    size_t spill_ints = (size_t)persistent_grid(ctx) * RT_BLOCK * RT_MAX_STACK * 2;
     HIP_OK(sc->d_spill.alloc(spill_ints * 4));
     DevScene &D = sc->dev;
     D.nodes = (const float4 *)sc->d_nodes.p; D.slots = (const float4 *)sc->d_slots.p; D.frames = (const float4 *)sc->d_frames.p;
     D.slot_uv = (const float *)sc->d_uv.p; D.spheres = (const float *)sc->d_spheres.p; D.slot_material = (const int *)sc->d_slot_mat.p;
     D.slot_light = (const int *)sc->d_slot_light.p; D.materials = (const DevMaterial *)sc->d_mats.p; D.textures = (const DevTexture *)sc->d_tex.p;
     D.lights = (const DevLight *)sc->d_lights.p; D.n_nodes = nn; D.n_slots = d->n_prims; D.n_lights = d->n_lights; D.pad = 0;
+    D.pairs = (const float4 *)sc->d_pairs.p; D.n_pairs = n_pairs;
+    memcpy(D.root_box, sc->nodes[0].bmin, 12); memcpy(D.root_box + 3, sc->nodes[0].bmax, 12);
+    D.root_info = childInfo(0);
     *out = sc.release();
     return 0;
 }
@@ -886,12 +985,12 @@ static int trace_host(rt_scene *this_, bool any, size_t n, const float *o, const
     char *base = (char *)this_->d_trace_io.p;
     HIP_OK(hipMemcpyAsync(base, rays.data(), in_bytes, hipMemcpyHostToDevice, ctx->stream));
     char *outp = base + ((in_bytes + 255) & ~(size_t)255);
-    int grid = (int)std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)persistent_grid(ctx));
+    int grid = (int)std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)ctx->n_cu * 5);
     if (any)
-        hipLaunchKernelGGL((k_trace_batch<true, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, (const float *)base, 1, nullptr, nullptr, nullptr,
+        hipLaunchKernelGGL((k_trace_pairs<true, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, (const float *)base, 1, nullptr, nullptr, nullptr,
                            nullptr, (uint8_t *)outp, (int *)this_->d_spill.p, nullptr);
     else
-        hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, (const float *)base, 1, (int *)outp,
+        hipLaunchKernelGGL((k_trace_pairs<false, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, (const float *)base, 1, (int *)outp,
                            (float *)outp + n, (float *)outp + 2 * n, (float *)outp + 3 * n, nullptr, (int *)this_->d_spill.p, nullptr);
     HIP_OK(hipGetLastError());
     if (any) HIP_OK(hipMemcpyAsync(out_hit, outp, n, hipMemcpyDeviceToHost, ctx->stream));
@@ -920,13 +1019,13 @@ int rt_trace_closest_device(rt_scene *this_, size_t n, const void *rays, void *h
     rt_ctx *ctx = this_->ctx;
     HIP_OK(hipSetDevice(ctx->device));
     if (repeats < 1) repeats = 1;
-    int grid = (int)std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)persistent_grid(ctx));
+    int grid = (int)std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)ctx->n_cu * 5);
     int *prim = (int *)hits; float *t = (float *)hits + n, *b1 = (float *)hits + 2 * n, *b2 = (float *)hits + 3 * n;
     if (stats) memset(stats, 0, sizeof(*stats));
     if (count_work) {
         HIP_OK(this_->d_work.ensure(16));
         HIP_OK(hipMemsetAsync(this_->d_work.p, 0, 16, ctx->stream));
-        hipLaunchKernelGGL((k_trace_batch<false, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, (const float *)rays, 0, prim, t, b1, b2, nullptr,
+        hipLaunchKernelGGL((k_trace_pairs<false, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, (const float *)rays, 0, prim, t, b1, b2, nullptr,
                            (int *)this_->d_spill.p, (unsigned long long *)this_->d_work.p);
         HIP_OK(hipGetLastError());
         unsigned long long w[2];
@@ -938,7 +1037,7 @@ int rt_trace_closest_device(rt_scene *this_, size_t n, const void *rays, void *h
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     HIP_OK(hipEventRecord(e0, ctx->stream));
     for (int r = 0; r < repeats; ++r)
-        hipLaunchKernelGGL((k_trace_batch<false, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, (const float *)rays, 0, prim, t, b1, b2, nullptr,
+        hipLaunchKernelGGL((k_trace_pairs<false, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, (const float *)rays, 0, prim, t, b1, b2, nullptr,
                            (int *)this_->d_spill.p, nullptr);
     HIP_OK(hipEventRecord(e1, ctx->stream));
     HIP_OK(hipEventSynchronize(e1));
