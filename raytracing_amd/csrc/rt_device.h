@@ -53,6 +53,8 @@ struct DevScene {
     int n_nodes, n_slots, n_lights, n_pairs;
     float root_box[6];        // bounds of node 0
     uint32_t root_info;       // pair index of the root, or a leaf code when the tree is a single leaf
+    const float4 *quads;      // 8 x float4 per even-depth interior node (rt_traverse2.h); null when the tree does not qualify
+    int n_quads, quad_stack_cap;
     uint32_t pad;
 };
 

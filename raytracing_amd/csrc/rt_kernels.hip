@@ -160,14 +160,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_batch(DevScene sc, size_t n,
 
 // Batch trace over pair nodes with persistent lanes (rt_traverse2.h).  Each wave owns a contiguous range of rays.
 #define RT_LEAF_MIN_LANES 12
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool QUAD>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_pairs(DevScene sc, size_t n, const float *__restrict__ rays, int aos, int *out_prim, float *out_t,
-                                                           float *out_b1, float *out_b2, uint8_t *out_any, int *spill, unsigned long long *work) {
+                                                           float *out_b1, float *out_b2, uint8_t *out_any, int *spill, unsigned long long *work, int leaf_min) {
     __shared__ int s_si[RT_PAIR_STACK * RT_BLOCK];
     __shared__ float s_st[RT_PAIR_STACK * RT_BLOCK];
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     PairStack st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
-    st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)RT_MAX_STACK * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
+    st.cap = QUAD ? sc.quad_stack_cap : RT_MAX_STACK;
+    st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     size_t nwaves = nthreads / RT_WAVE, gw = gtid / RT_WAVE;
     size_t per = ((n + nwaves - 1) / nwaves + RT_WAVE - 1) & ~(size_t)(RT_WAVE - 1);
     size_t w_lo = gw * per < n ? gw * per : n, w_hi = w_lo + per < n ? w_lo + per : n;
@@ -218,10 +219,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_pairs(DevScene sc, size_t n,
         }
         if (__ballot(ri >= 0) == 0) break;
         bool act = ri >= 0 && !pending;
-        if (act && L.mode == RT_LANE_WALK) lane_walk<COUNT>(sc, L, st, nNodes);
+        if (act && L.mode == RT_LANE_WALK) {
+            if (QUAD) lane_walk_quad(sc, L, st);
+            else lane_walk<COUNT>(sc, L, st, nNodes);
+        }
         bool leaf = act && L.mode == RT_LANE_LEAF;
         uint64_t lm = __ballot(leaf), wm = __ballot(act && L.mode == RT_LANE_WALK);
-        if (lm != 0 && (__popcll(lm) >= RT_LEAF_MIN_LANES || wm == 0)) {
+        if (lm != 0 && (__popcll(lm) >= leaf_min || wm == 0)) {
             if (leaf) lane_leaf<ANY, COUNT>(sc, L, st, nTests);
         }
     }
@@ -723,7 +727,7 @@ struct rt_scene {
     std::vector<rt_bvh_node> nodes; std::vector<int32_t> order;
     int n_prims = 0;
     bool classes[RT_NUM_CLASSES] = {false, false, false, false, false, false};
-    DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_spill, d_pairs;
+    DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_spill, d_pairs, d_quads;
     std::vector<DevBuf *> d_texels;
     // render workspace
     DevBuf d_q[2], d_hits, d_cls, d_shadow, d_lbuf, d_counters, d_sum, d_trace_io, d_work;
@@ -734,6 +738,9 @@ struct rt_scene {
 static rt_ctx *ctx_of(rt_ctx *c) { return c; }
 static rt_ctx *ctx_of(rt_scene *s) { return s ? s->ctx : nullptr; }
 
+static int env_int(const char *name, int def) { const char *v = getenv(name); return v && *v ? atoi(v) : def; }
+static int tune_leaf_min() { return env_int("RT_AMD_LEAF_MIN", RT_LEAF_MIN_LANES); }
+static int trace_blocks_per_cu() { int v = env_int("RT_AMD_TRACE_BLOCKS_PER_CU", 4); return v < 1 ? 1 : (v > 8 ? 8 : v); }
 static int persistent_grid(rt_ctx *c) { return c->n_cu * 8; }   // batch trace kernels (grid-stride)
 
 namespace {
@@ -944,7 +951,63 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
         memcpy(P + 12, &il, 4); memcpy(P + 13, &ir, 4); memcpy(P + 14, &axis, 4);
     }
     HIP_OK(up(sc->d_pairs, pairs.data(), pairs.size() * 4));
-    size_t spill_ints = (size_t)persistent_grid(ctx) * RT_BLOCK * RT_MAX_STACK * 2;
+    // quad nodes: one 128-byte record per even-depth interior node with the boxes of its four grandchildren.  Only for trees
+    // whose interior boxes are bit for bit the min/max of their children's (true of every tree rt_bvh_build makes).
+    std::vector<float> quads;
+    int n_quads = 0, tree_depth = 0;
+    bool quads_ok = sc->nodes[0].nprim == 0;
+    if (quads_ok) {
+        std::vector<int32_t> quadIndex(nn, -1);
+        struct Visit { int node, depth; };
+        std::vector<Visit> todo; todo.push_back({0, 0});
+        std::vector<int> quadNodes;
+        while (!todo.empty()) {           // pre-order over even-depth interior nodes, near subtrees contiguous
+            Visit v = todo.back(); todo.pop_back();
+            tree_depth = std::max(tree_depth, v.depth);
+            quadIndex[v.node] = n_quads++; quadNodes.push_back(v.node);
+            int kids[2] = {v.node + 1, sc->nodes[v.node].offset};
+            int grand[4]; int ng = 0;
+            for (int k = 0; k < 2; ++k)
+                if (sc->nodes[kids[k]].nprim == 0) { grand[ng++] = kids[k] + 1; grand[ng++] = sc->nodes[kids[k]].offset; tree_depth = std::max(tree_depth, v.depth + 1); }
+            for (int g = ng - 1; g >= 0; --g)
+                if (sc->nodes[grand[g]].nprim == 0) todo.push_back({grand[g], v.depth + 2});
+        }
+        auto quadInfo = [&](int c) -> uint32_t {
+            const rt_bvh_node &nd = sc->nodes[c];
+            if (nd.nprim == 0) return (uint32_t)quadIndex[c];
+            if (nd.nprim == 1) return RT_PAIR_LEAF | (uint32_t)nd.offset;
+            return RT_PAIR_LEAF_MULTI | (uint32_t)c;
+        };
+        quads.assign(32 * (size_t)n_quads, 0.f);
+        for (int qi = 0; qi < n_quads && quads_ok; ++qi) {
+            int p = quadNodes[qi];
+            float *Q = &quads[32 * (size_t)qi];
+            uint32_t meta = (uint32_t)sc->nodes[p].axis & 3u, info[4] = {RT_QUAD_NONE, RT_QUAD_NONE, RT_QUAD_NONE, RT_QUAD_NONE};
+            int kids[2] = {p + 1, sc->nodes[p].offset};
+            for (int k = 0; k < 2; ++k) {
+                const rt_bvh_node &c = sc->nodes[kids[k]];
+                float *B = Q + 12 * k;
+                if (c.nprim != 0) {
+                    memcpy(B, c.bmin, 12); memcpy(B + 3, c.bmax, 12);
+                    info[2 * k] = quadInfo(kids[k]);
+                    meta |= 64u << k;
+                } else {
+                    const rt_bvh_node &a = sc->nodes[kids[k] + 1], &b = sc->nodes[c.offset];
+                    memcpy(B, a.bmin, 12); memcpy(B + 3, a.bmax, 12); memcpy(B + 6, b.bmin, 12); memcpy(B + 9, b.bmax, 12);
+                    info[2 * k] = quadInfo(kids[k] + 1); info[2 * k + 1] = quadInfo(c.offset);
+                    meta |= ((uint32_t)c.axis & 3u) << (2 + 2 * k);
+                    float u[6];
+                    for (int j = 0; j < 3; ++j) { u[j] = b.bmin[j] < a.bmin[j] ? b.bmin[j] : a.bmin[j]; u[3 + j] = a.bmax[j] < b.bmax[j] ? b.bmax[j] : a.bmax[j]; }
+                    if (memcmp(u, c.bmin, 12) != 0 || memcmp(u + 3, c.bmax, 12) != 0) quads_ok = false;
+                }
+            }
+            memcpy(Q + 24, info, 16); memcpy(Q + 28, &meta, 4);
+        }
+    }
+    if (env_int("RT_AMD_NO_QUADS", 0)) quads_ok = false;
+    int quad_cap = 3 * (tree_depth / 2 + 1) + 2;      // at most three pushes per record on the path from the root
+    if (quads_ok) HIP_OK(up(sc->d_quads, quads.data(), quads.size() * 4));
+    size_t spill_ints = (size_t)persistent_grid(ctx) * RT_BLOCK * (size_t)std::max(RT_MAX_STACK, quads_ok ? quad_cap : 0) * 2;
     HIP_OK(sc->d_spill.alloc(spill_ints * 4));
     DevScene &D = sc->dev;
     D.nodes = (const float4 *)sc->d_nodes.p; D.slots = (const float4 *)sc->d_slots.p; D.frames = (const float4 *)sc->d_frames.p;
@@ -954,6 +1017,7 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     D.pairs = (const float4 *)sc->d_pairs.p; D.n_pairs = n_pairs;
     memcpy(D.root_box, sc->nodes[0].bmin, 12); memcpy(D.root_box + 3, sc->nodes[0].bmax, 12);
     D.root_info = childInfo(0);
+    D.quads = quads_ok ? (const float4 *)sc->d_quads.p : nullptr; D.n_quads = quads_ok ? n_quads : 0; D.quad_stack_cap = quad_cap;
     *out = sc.release();
     return 0;
 }
@@ -973,6 +1037,22 @@ int rt_scene_get_bvh(rt_scene *this_, rt_bvh_node *nodes_out, int32_t *n_nodes_o
     return 0;
 }
 
+// Batch trace launch: quad records when the scene has them, pair records otherwise and for the counting variant (whose
+// counts are the reference's per-node and per-primitive test counts).
+extern "C++" {
+template <bool ANY, bool COUNT>
+static void launch_trace(rt_scene *this_, int grid, size_t n, const float *rays, int aos, int *prim, float *t, float *b1, float *b2, uint8_t *any_out,
+                         unsigned long long *work) {
+    rt_ctx *ctx = this_->ctx;
+    if (!COUNT && this_->dev.quads)
+        hipLaunchKernelGGL((k_trace_pairs<ANY, false, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
+                           (int *)this_->d_spill.p, work, tune_leaf_min());
+    else
+        hipLaunchKernelGGL((k_trace_pairs<ANY, COUNT, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
+                           (int *)this_->d_spill.p, work, tune_leaf_min());
+}
+}
+
 static int trace_host(rt_scene *this_, bool any, size_t n, const float *o, const float *d, const float *tmax, int32_t *out_prim, float *out_t, float *out_b,
                       uint8_t *out_hit) {
     rt_ctx *ctx = this_->ctx;
@@ -985,13 +1065,12 @@ static int trace_host(rt_scene *this_, bool any, size_t n, const float *o, const
     char *base = (char *)this_->d_trace_io.p;
     HIP_OK(hipMemcpyAsync(base, rays.data(), in_bytes, hipMemcpyHostToDevice, ctx->stream));
     char *outp = base + ((in_bytes + 255) & ~(size_t)255);
-    int grid = (int)std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)ctx->n_cu * 5);
+    int grid = (int)std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)ctx->n_cu * trace_blocks_per_cu());
     if (any)
-        hipLaunchKernelGGL((k_trace_pairs<true, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, (const float *)base, 1, nullptr, nullptr, nullptr,
-                           nullptr, (uint8_t *)outp, (int *)this_->d_spill.p, nullptr);
+        launch_trace<true, false>(this_, grid, n, (const float *)base, 1, nullptr, nullptr, nullptr, nullptr, (uint8_t *)outp, nullptr);
     else
-        hipLaunchKernelGGL((k_trace_pairs<false, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, (const float *)base, 1, (int *)outp,
-                           (float *)outp + n, (float *)outp + 2 * n, (float *)outp + 3 * n, nullptr, (int *)this_->d_spill.p, nullptr);
+        launch_trace<false, false>(this_, grid, n, (const float *)base, 1, (int *)outp, (float *)outp + n, (float *)outp + 2 * n, (float *)outp + 3 * n, nullptr,
+                                   nullptr);
     HIP_OK(hipGetLastError());
     if (any) HIP_OK(hipMemcpyAsync(out_hit, outp, n, hipMemcpyDeviceToHost, ctx->stream));
     else {
@@ -1019,14 +1098,13 @@ int rt_trace_closest_device(rt_scene *this_, size_t n, const void *rays, void *h
     rt_ctx *ctx = this_->ctx;
     HIP_OK(hipSetDevice(ctx->device));
     if (repeats < 1) repeats = 1;
-    int grid = (int)std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)ctx->n_cu * 5);
+    int grid = (int)std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)ctx->n_cu * trace_blocks_per_cu());
     int *prim = (int *)hits; float *t = (float *)hits + n, *b1 = (float *)hits + 2 * n, *b2 = (float *)hits + 3 * n;
     if (stats) memset(stats, 0, sizeof(*stats));
     if (count_work) {
         HIP_OK(this_->d_work.ensure(16));
         HIP_OK(hipMemsetAsync(this_->d_work.p, 0, 16, ctx->stream));
-        hipLaunchKernelGGL((k_trace_pairs<false, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, (const float *)rays, 0, prim, t, b1, b2, nullptr,
-                           (int *)this_->d_spill.p, (unsigned long long *)this_->d_work.p);
+        launch_trace<false, true>(this_, grid, n, (const float *)rays, 0, prim, t, b1, b2, nullptr, (unsigned long long *)this_->d_work.p);
         HIP_OK(hipGetLastError());
         unsigned long long w[2];
         HIP_OK(hipMemcpyAsync(w, this_->d_work.p, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -1037,8 +1115,7 @@ int rt_trace_closest_device(rt_scene *this_, size_t n, const void *rays, void *h
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     HIP_OK(hipEventRecord(e0, ctx->stream));
     for (int r = 0; r < repeats; ++r)
-        hipLaunchKernelGGL((k_trace_pairs<false, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, (const float *)rays, 0, prim, t, b1, b2, nullptr,
-                           (int *)this_->d_spill.p, nullptr);
+        launch_trace<false, false>(this_, grid, n, (const float *)rays, 0, prim, t, b1, b2, nullptr, nullptr);
     HIP_OK(hipEventRecord(e1, ctx->stream));
     HIP_OK(hipEventSynchronize(e1));
     HIP_OK(hipGetLastError());

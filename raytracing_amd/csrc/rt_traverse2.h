@@ -10,6 +10,11 @@
 //     comparison on the same numbers.  A far child that already fails is never pushed (ray.tMax only shrinks).
 //   * Persistent lanes.  A wave owns a contiguous range of rays; a lane whose ray is finished takes the next one, so a wave
 //     never idles 63 lanes behind its longest ray.
+//   * Quad nodes.  HBM serves a random 128-byte line as fast as a random 64-byte half line (the request rate, not the byte
+//     rate, is the ceiling for scattered reads), so the batch kernels walk TWO tree levels per round trip: one 128-byte
+//     record per even-depth interior node holds the boxes of its four grandchildren.  The children's boxes are rebuilt from
+//     them (a parent's box is the exact componentwise min/max of its children's, bvh.cpp:30-34), so every slab test the
+//     reference evaluates is evaluated here on the same numbers, and the visit order is the reference's.
 //   * Leaf postponing.  Lanes that reach a leaf wait until enough lanes hold one (or nobody can walk), then the
 //     primitive tests run together.
 #pragma once
@@ -23,11 +28,12 @@ struct PairStack {
     int *lds_i; float *lds_t;       // &shared[0][threadIdx.x], stride RT_BLOCK
     int *spill_i; float *spill_t;   // &spill[0][global thread], stride spill_stride
     size_t spill_stride;
+    int cap;                        // entries the spill area holds per lane
     int sp, lo;                     // entries [lo, sp) are in the ring
     __device__ __forceinline__ void reset() { sp = 0; lo = 0; }
     __device__ __forceinline__ void push(int info, float t) {
         if (sp - lo == RT_PAIR_STACK) {
-            if (lo < RT_MAX_STACK) {
+            if (lo < cap) {
                 int k = (lo & (RT_PAIR_STACK - 1)) * RT_BLOCK;
                 spill_i[(size_t)lo * spill_stride] = lds_i[k]; spill_t[(size_t)lo * spill_stride] = lds_t[k];
             }
@@ -41,7 +47,7 @@ struct PairStack {
         sp--;
         if (sp < lo) {
             lo = sp;
-            if (sp < RT_MAX_STACK) { info = spill_i[(size_t)sp * spill_stride]; t = spill_t[(size_t)sp * spill_stride]; }
+            if (sp < cap) { info = spill_i[(size_t)sp * spill_stride]; t = spill_t[(size_t)sp * spill_stride]; }
             else { info = 0; t = RT_INF; }
             return;
         }
@@ -141,6 +147,58 @@ __device__ __forceinline__ void lane_walk(const DevScene &sc, LaneTrav &L, PairS
     else if (okF) lane_enter(sc, L, infoF);
     else lane_pop_next(sc, L, st);
 }
+// ---- quad nodes ----
+// Record layout (8 x float4): boxes of LL, LR, RL, RR (6 floats each: min xyz, max xyz) | info[4] | meta | 3 spare words.
+// A child that is itself a leaf occupies the first box of its side; the second info of that side is RT_QUAD_NONE.
+// meta: bits 0-1 split axis of the node, 2-3 of its left child, 4-5 of its right child, bit 6 left child is a leaf,
+// bit 7 right child is a leaf.
+#define RT_QUAD_NONE 0xFFFFFFFFu
+struct QuadCand { uint32_t info; float t; bool ok; };
+
+// One side of a quad: child box C = union(A, B) (or A when the child is a leaf).  Produces the side's candidates in visit
+// order.  A candidate is kept when every tMax-independent condition of the reference's tests on its ancestors inside the
+// record and on itself holds and its own tMin is below the ray's current tMax; tMin travels with the candidate so that
+// the comparison against the ray's tMax of the moment the reference would test it is made at pop time.  The child's own
+// comparison needs no replay at pop time: tMin(child) <= tMin(grandchild) because the boxes nest and the slab arithmetic is
+// monotonic, and tMax only shrinks; a NaN tMin(child) rejects the child for every tMax, here as there.
+__device__ __forceinline__ void quad_side(const LaneTrav &L, float a0, float a1, float a2, float a3, float a4, float a5, float b0, float b1, float b2, float b3,
+                                          float b4, float b5, uint32_t iA, uint32_t iB, bool leaf, int axis, QuadCand &c0, QuadCand &c1) {
+    // Union(b1, b2) with std::min / std::max argument order (geometry.h:833-840)
+    float cx0 = b0 < a0 ? b0 : a0, cy0 = b1 < a1 ? b1 : a1, cz0 = b2 < a2 ? b2 : a2;
+    float cx1 = a3 < b3 ? b3 : a3, cy1 = a4 < b4 ? b4 : a4, cz1 = a5 < b5 ? b5 : a5;
+    float tA, tB, tC;
+    bool okA = slab_partial(a0, a1, a2, a3, a4, a5, L.o, L.invDir, L.negx, L.negy, L.negz, tA);
+    bool okB = slab_partial(b0, b1, b2, b3, b4, b5, L.o, L.invDir, L.negx, L.negy, L.negz, tB);
+    bool okC = slab_partial(cx0, cy0, cz0, cx1, cy1, cz1, L.o, L.invDir, L.negx, L.negy, L.negz, tC);
+    okA = okA && tA < L.tmax; okB = okB && tB < L.tmax; okC = okC && tC < L.tmax;
+    if (leaf) { c0.info = iA; c0.t = tA; c0.ok = okA; c1.info = RT_QUAD_NONE; c1.t = 0.f; c1.ok = false; return; }
+    int neg = axis == 0 ? L.negx : (axis == 1 ? L.negy : L.negz);
+    c0.info = neg ? iB : iA; c0.t = neg ? tB : tA; c0.ok = okC && (neg ? okB : okA);
+    c1.info = neg ? iA : iB; c1.t = neg ? tA : tB; c1.ok = okC && (neg ? okA : okB);
+}
+
+// One interior step over quad node L.cur: the node's two children and four grandchildren.
+__device__ __forceinline__ void lane_walk_quad(const DevScene &sc, LaneTrav &L, PairStack &st) {
+    const float4 *Q = sc.quads + 8 * (size_t)L.cur;
+    float4 q0 = Q[0], q1 = Q[1], q2 = Q[2], q3 = Q[3], q4 = Q[4], q5 = Q[5], q6 = Q[6];
+    uint32_t meta = ((const uint32_t *)Q)[28];
+    QuadCand l0, l1, r0, r1;
+    quad_side(L, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, __float_as_uint(q6.x), __float_as_uint(q6.y), (meta & 64u) != 0,
+              (int)((meta >> 2) & 3u), l0, l1);
+    quad_side(L, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, __float_as_uint(q6.z), __float_as_uint(q6.w), (meta & 128u) != 0,
+              (int)((meta >> 4) & 3u), r0, r1);
+    int axis = (int)(meta & 3u);
+    int neg = axis == 0 ? L.negx : (axis == 1 ? L.negy : L.negz);
+    // visit order: near child's candidates, then the far child's (bvh.cpp:266-273)
+    QuadCand c0 = neg ? r0 : l0, c1 = neg ? r1 : l1, c2 = neg ? l0 : r0, c3 = neg ? l1 : r1;
+    int first = c0.ok ? 0 : (c1.ok ? 1 : (c2.ok ? 2 : (c3.ok ? 3 : 4)));
+    if (c3.ok && first < 3) st.push((int)c3.info, c3.t);
+    if (c2.ok && first < 2) st.push((int)c2.info, c2.t);
+    if (c1.ok && first < 1) st.push((int)c1.info, c1.t);
+    if (first == 4) lane_pop_next(sc, L, st);
+    else lane_enter(sc, L, first == 0 ? c0.info : (first == 1 ? c1.info : (first == 2 ? c2.info : c3.info)));
+}
+
 // Test the primitives of the pending leaf (bvh.cpp:258-261 / 294-299), then move on.
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void lane_leaf(const DevScene &sc, LaneTrav &L, PairStack &st, uint32_t &nTests) {
