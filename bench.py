@@ -52,7 +52,7 @@ def traversal_roofline(ctx, n_tris, n_rays, repeats):
     bytes_per_launch = 32.0 * nodes + 36.0 * tests + 48.0 * n_rays
     achieved = bytes_per_launch / st.seconds / 1e9
     prim = hits[0].view(torch.int32)
-    out = {"bound": "hbm", "kernel": "k_trace_pairs<closest>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    out = {"bound": "hbm", "kernel": "k_trace_pairs<closest, quad records>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
            "workload": "%d-triangle soup, %d incoherent rays" % (n_tris, n_rays),
            "bytes_per_ray": round(bytes_per_launch / n_rays, 1), "nodes_per_ray": round(nodes / n_rays, 2), "tris_per_ray": round(tests / n_rays, 2),
@@ -68,15 +68,18 @@ def cpu_baseline(scene):
     cores = min(os.cpu_count() or 1, 16)
     osc = ol.OracleScene(scene.desc_ptr)
     cam = scene.camera(W, H)
-    spp = 4
     t0 = time.time()
     osc.render(cam, ra.make_opts(2, 2), mode=0, threads=cores)
     dt = time.time() - t0
-    if dt < 5.0:   # bound the sample to roughly 10-30 s of CPU work
-        spp = 16
-        t0 = time.time()
-        osc.render(cam, ra.make_opts(4, 4), mode=0, threads=cores)
-        dt = time.time() - t0
+    spp = 4
+    # bound the sample to roughly 10-30 s of CPU work: the largest strata grid whose projected time stays under 25 s
+    for sx, sy in ((16, 16), (16, 8), (8, 8), (8, 4), (4, 4)):
+        if dt / 4 * sx * sy <= 25.0:
+            spp = sx * sy
+            t0 = time.time()
+            osc.render(cam, ra.make_opts(sx, sy), mode=0, threads=cores)
+            dt = time.time() - t0
+            break
     osc.close()
     return {"value": round(W * H * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": "Cornell 800x800 @ %d spp (%.1f s); CPU restatement of the reference's recursive renderer, bit-exact with it" % (spp, dt)}

@@ -159,14 +159,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_batch(DevScene sc, size_t n,
 }
 
 // Batch trace over pair nodes with persistent lanes (rt_traverse2.h).  Each wave owns a contiguous range of rays.
-#define RT_LEAF_MIN_LANES 12
+#define RT_LEAF_MIN_LANES 20
 template <bool ANY, bool COUNT, bool QUAD>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_pairs(DevScene sc, size_t n, const float *__restrict__ rays, int aos, int *out_prim, float *out_t,
+__global__ __launch_bounds__(RT_BLOCK, 5) void k_trace_pairs(DevScene sc, size_t n, const float *__restrict__ rays, int aos, int *out_prim, float *out_t,
                                                            float *out_b1, float *out_b2, uint8_t *out_any, int *spill, unsigned long long *work, int leaf_min) {
-    __shared__ int s_si[RT_PAIR_STACK * RT_BLOCK];
-    __shared__ float s_st[RT_PAIR_STACK * RT_BLOCK];
+    constexpr int RING = QUAD ? RT_QUAD_STACK : RT_PAIR_STACK;
+    __shared__ int s_si[RING * RT_BLOCK];
+    __shared__ float s_st[RING * RT_BLOCK];
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    PairStack st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
+    PairStackT<RING> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
     st.cap = QUAD ? sc.quad_stack_cap : RT_MAX_STACK;
     st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     size_t nwaves = nthreads / RT_WAVE, gw = gtid / RT_WAVE;
@@ -174,12 +175,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_pairs(DevScene sc, size_t n,
     size_t w_lo = gw * per < n ? gw * per : n, w_hi = w_lo + per < n ? w_lo + per : n;
     size_t next = w_lo;
     long long ri = -1;
-    bool pending = false;
-    F3 po = f3(0, 0, 0), pd = f3(0, 0, 1); float ptmax = 0.f;
-    LaneTrav L; L.mode = RT_LANE_DONE; L.found = false; L.hitSlot = -1; L.tmax = 0.f; L.b0 = L.b1 = L.b2 = 0.f;
+    LaneTrav L = {};
+    L.mode = RT_LANE_DONE; L.hitSlot = -1;
     uint32_t nNodes = 0, nTests = 0;
+    const bool exact_slabs = (leaf_min >> 8) & 1;    // knob: every wave takes the general slab path
+    leaf_min &= 255;
     while (true) {
-        if (pending) { lane_begin<COUNT>(sc, L, st, po, pd, ptmax, nNodes); pending = false; }
         if (ri >= 0 && L.mode == RT_LANE_DONE) {   // retire
             size_t i = (size_t)ri;
             if (ANY) out_any[i] = L.found ? 1 : 0;
@@ -203,31 +204,38 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_pairs(DevScene sc, size_t n,
             }
             ri = -1;
         }
-        bool idle = ri < 0;
-        uint64_t im = __ballot(idle);
+        // refill: idle lanes take the next rays of the wave's range; the loads are consumed at the end of this iteration
+        bool fresh = false;
+        F3 po = f3(0, 0, 0), pd = f3(0, 0, 1); float ptmax = 0.f;
+        uint64_t im = __ballot(ri < 0);
         if (im != 0 && next < w_hi) {
-            uint32_t rank = prefix_in_mask(im);
-            size_t cand = next + rank;
-            if (idle && cand < w_hi) {
+            size_t cand = next + prefix_in_mask(im);
+            if (ri < 0 && cand < w_hi) {
                 ri = (long long)cand;
                 size_t i = cand;
                 if (aos) { po = f3(rays[7 * i], rays[7 * i + 1], rays[7 * i + 2]); pd = f3(rays[7 * i + 3], rays[7 * i + 4], rays[7 * i + 5]); ptmax = rays[7 * i + 6]; }
                 else { po = f3(rays[i], rays[n + i], rays[2 * n + i]); pd = f3(rays[3 * n + i], rays[4 * n + i], rays[5 * n + i]); ptmax = rays[6 * n + i]; }
-                pending = true;
+                fresh = true;
             }
             next += __popcll(im);
         }
         if (__ballot(ri >= 0) == 0) break;
-        bool act = ri >= 0 && !pending;
-        if (act && L.mode == RT_LANE_WALK) {
-            if (QUAD) lane_walk_quad(sc, L, st);
-            else lane_walk<COUNT>(sc, L, st, nNodes);
+        // a fresh lane still shows the finished state of its previous ray, so it neither walks nor tests a leaf below
+        uint32_t info = 0; bool have = false;
+        bool walk = L.mode == RT_LANE_WALK, leaf = L.mode == RT_LANE_LEAF;
+        uint64_t lm = __ballot(leaf), wm = __ballot(walk);
+        if (QUAD) {
+            if (__ballot(walk && !L.plain) == 0 && !exact_slabs) { if (walk) lane_walk_quad<true>(sc, L, st, info, have); }     // the whole wave takes one version
+            else if (walk) lane_walk_quad<false>(sc, L, st, info, have);
+        } else if (walk) lane_walk<COUNT>(sc, L, st, nNodes, info, have);
+        bool leafrun = leaf && (__popcll(lm) >= leaf_min || wm == 0);
+        if (leafrun) {
+            LeafOut r = lane_leaf<ANY, COUNT>(sc, L, st, nTests);
+            L.found = r.found; L.tmax = r.tmax; L.hitSlot = r.hitSlot; L.b0 = r.b0; L.b1 = r.b1; L.b2 = r.b2;
+            info = r.info; have = r.have;
         }
-        bool leaf = act && L.mode == RT_LANE_LEAF;
-        uint64_t lm = __ballot(leaf), wm = __ballot(act && L.mode == RT_LANE_WALK);
-        if (lm != 0 && (__popcll(lm) >= leaf_min || wm == 0)) {
-            if (leaf) lane_leaf<ANY, COUNT>(sc, L, st, nTests);
-        }
+        if (fresh) { have = lane_begin<COUNT>(sc, L, st, po, pd, ptmax, nNodes); info = sc.root_info; }
+        if (walk || leafrun || fresh) lane_enter(sc, L, info, have);
     }
     if (COUNT) {
         atomicAdd(&work[0], (unsigned long long)nNodes);
@@ -739,7 +747,7 @@ static rt_ctx *ctx_of(rt_ctx *c) { return c; }
 static rt_ctx *ctx_of(rt_scene *s) { return s ? s->ctx : nullptr; }
 
 static int env_int(const char *name, int def) { const char *v = getenv(name); return v && *v ? atoi(v) : def; }
-static int tune_leaf_min() { return env_int("RT_AMD_LEAF_MIN", RT_LEAF_MIN_LANES); }
+static int tune_leaf_min() { return (env_int("RT_AMD_LEAF_MIN", RT_LEAF_MIN_LANES) & 255) | (env_int("RT_AMD_EXACT_SLABS", 0) ? 256 : 0); }
 static int trace_blocks_per_cu() { int v = env_int("RT_AMD_TRACE_BLOCKS_PER_CU", 4); return v < 1 ? 1 : (v > 8 ? 8 : v); }
 static int persistent_grid(rt_ctx *c) { return c->n_cu * 8; }   // batch trace kernels (grid-stride)
 
@@ -988,7 +996,7 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
                 const rt_bvh_node &c = sc->nodes[kids[k]];
                 float *B = Q + 12 * k;
                 if (c.nprim != 0) {
-                    memcpy(B, c.bmin, 12); memcpy(B + 3, c.bmax, 12);
+                    memcpy(B, c.bmin, 12); memcpy(B + 3, c.bmax, 12); memcpy(B + 6, c.bmin, 12); memcpy(B + 9, c.bmax, 12);
                     info[2 * k] = quadInfo(kids[k]);
                     meta |= 64u << k;
                 } else {
@@ -1044,7 +1052,10 @@ template <bool ANY, bool COUNT>
 static void launch_trace(rt_scene *this_, int grid, size_t n, const float *rays, int aos, int *prim, float *t, float *b1, float *b2, uint8_t *any_out,
                          unsigned long long *work) {
     rt_ctx *ctx = this_->ctx;
-    if (!COUNT && this_->dev.quads)
+    if (env_int("RT_AMD_NODE_WALK", 0))      // knob: the one-node-per-step walk the frame kernels use
+        hipLaunchKernelGGL((k_trace_batch<ANY, COUNT>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
+                           (int *)this_->d_spill.p, work);
+    else if (!COUNT && this_->dev.quads)
         hipLaunchKernelGGL((k_trace_pairs<ANY, false, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
                            (int *)this_->d_spill.p, work, tune_leaf_min());
     else

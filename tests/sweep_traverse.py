@@ -16,8 +16,10 @@ def run(tag):
     ds.trace_closest_device(n_rays, rays.data_ptr(), hits.data_ptr(), repeats=1)
     st = ds.trace_closest_device(n_rays, rays.data_ptr(), hits.data_ptr(), repeats=3)
     print("%-28s %8.2f ms  %7.1f Mrays/s" % (tag, st.seconds * 1e3, n_rays / st.seconds / 1e6), flush=True)
-for lm in (1, 4, 8, 12, 20, 32, 48, 64):
+for lm in (20,):
     os.environ["RT_AMD_LEAF_MIN"] = str(lm); run("leaf_min=%d" % lm)
-os.environ["RT_AMD_LEAF_MIN"] = "12"
-for b in (2, 3, 4, 5):
+os.environ["RT_AMD_LEAF_MIN"] = "20"
+for b in (4, 5, 4, 5):
     os.environ["RT_AMD_TRACE_BLOCKS_PER_CU"] = str(b); run("blocks_per_cu=%d" % b)
+os.environ["RT_AMD_EXACT_SLABS"] = "1"; run("bpc4 exact slabs")
+os.environ["RT_AMD_EXACT_SLABS"] = "0"

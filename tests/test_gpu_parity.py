@@ -57,6 +57,54 @@ def test_traversal_bit_exact_vs_oracle_random_rays(name, lo, hi, device_scene, o
     assert np.array_equal(device_scene(name, param).trace_any(o, d, tmax), oracle_scene(name, param).trace_any(o, d, tmax))
 
 
+@pytest.mark.parametrize("name", ["cornell", "sphere1", "helmet"])
+def test_traversal_rays_on_box_planes(name, device_scene, oracle_scene, host_scene):
+    """Origins ON bounding planes of tree nodes with directions that have zero components: 0 * inf = NaN inside the slab
+    test (geometry.h:895-914).  The device must reject and accept exactly the nodes the reference does."""
+    ds = device_scene(name)
+    nodes, _ = ds.get_bvh(host_scene(name).desc.n_prims)
+    rng = np.random.default_rng(7)
+    n = 60000
+    pick = rng.integers(0, len(nodes), n)
+    planes = np.concatenate([nodes["bmin"][pick], nodes["bmax"][pick]], axis=1)          # (n, 6) plane coordinates of real nodes
+    o = np.stack([planes[np.arange(n), rng.integers(0, 2, n) * 3 + k] for k in range(3)], axis=1).astype(np.float32)
+    keep = rng.random((n, 3)) < 0.5                                                      # some coordinates off the planes
+    o = np.where(keep, o, o + rng.normal(size=(n, 3)).astype(np.float32)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[rng.random((n, 3)) < 0.45] = 0
+    d[(d == 0).all(axis=1)] = [0, 0, -1]
+    d[: n // 8] = np.sign(d[: n // 8]) + (d[: n // 8] == 0) * 0.0                         # exact +-1 / 0 directions
+    d[(d == 0).all(axis=1)] = [1, 0, 0]
+    tmax = np.full(n, np.inf, np.float32)
+    prim, t, _ = ds.trace_closest(o, d, tmax)
+    p2, t2, _, _, _ = oracle_scene(name).trace_closest(o, d, tmax)
+    assert np.array_equal(prim, p2) and np.array_equal(t.view(np.uint32), t2.view(np.uint32))
+    assert np.array_equal(ds.trace_any(o, d, tmax), oracle_scene(name).trace_any(o, d, tmax))
+
+
+def test_traversal_variants_agree(host_scene, gpu_ctx, monkeypatch):
+    """The batch trace kernels have three walks over the same tree (quad records with the plain-ray slab test, quad records
+    with the general slab test, pair records); all must return the same bits."""
+    hs = host_scene("soup", 200000)
+    rng = np.random.default_rng(5)
+    n = 200000
+    o = rng.uniform(-5, 105, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    tmax = np.full(n, np.inf, np.float32); tmax[:20000] = rng.uniform(0, 30, 20000).astype(np.float32)
+    ds = ra.DeviceScene(gpu_ctx, hs.desc_ptr)
+    base = ds.trace_closest(o, d, tmax); base_any = ds.trace_any(o, d, tmax)
+    monkeypatch.setenv("RT_AMD_EXACT_SLABS", "1")
+    alt = ds.trace_closest(o, d, tmax); alt_any = ds.trace_any(o, d, tmax)
+    monkeypatch.delenv("RT_AMD_EXACT_SLABS")
+    monkeypatch.setenv("RT_AMD_NO_QUADS", "1")
+    ds2 = ra.DeviceScene(gpu_ctx, hs.desc_ptr)
+    monkeypatch.delenv("RT_AMD_NO_QUADS")
+    pair = ds2.trace_closest(o, d, tmax); pair_any = ds2.trace_any(o, d, tmax)
+    for other, other_any in ((alt, alt_any), (pair, pair_any)):
+        assert np.array_equal(base[0], other[0]) and np.array_equal(base[1].view(np.uint32), other[1].view(np.uint32))
+        assert np.array_equal(base[2].view(np.uint32), other[2].view(np.uint32)) and np.array_equal(base_any, other_any)
+
+
 def test_trace_edge_cases(device_scene):
     ds = device_scene("cornell")
     e = np.zeros((0, 3), np.float32)
