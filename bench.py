@@ -52,8 +52,20 @@ def traversal_roofline(ctx, n_tris, n_rays, repeats):
     bytes_per_launch = 32.0 * nodes + 36.0 * tests + 48.0 * n_rays
     achieved = bytes_per_launch / st.seconds / 1e9
     prim = hits[0].view(torch.int32)
+    # HBM traffic per launch comes from PMC passes (rocprofv3 cannot wrap its own caller): profiles/*_traverse_traffic.json holds
+    # the counters of the same kernel on the same workload; reported only when the workload matches, else null.
+    traffic = None; traffic_src = None
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traverse_traffic.json"))):
+            rec = json.load(open(f))
+            if rec["workload"] == {"n_tris": n_tris, "n_rays": n_rays}:
+                traffic = float(rec["traffic_bytes_per_launch"]); traffic_src = os.path.relpath(f, ROOT)
+    except Exception:
+        traffic = None
     out = {"bound": "hbm", "kernel": "k_trace_pairs<closest, quad records>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch (PMC, %s)" % traffic_src if traffic else None,
+           "algorithmic_bytes_per_launch": bytes_per_launch,
            "workload": "%d-triangle soup, %d incoherent rays" % (n_tris, n_rays),
            "bytes_per_ray": round(bytes_per_launch / n_rays, 1), "nodes_per_ray": round(nodes / n_rays, 2), "tris_per_ray": round(tests / n_rays, 2),
            "launch_ms": round(st.seconds * 1e3, 3), "mrays_per_s": round(n_rays / st.seconds / 1e6, 1),
