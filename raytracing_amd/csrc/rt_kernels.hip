@@ -34,7 +34,7 @@
 
 #define RT_NUM_CLASSES 6
 #define RT_BATCH_STACK 32       // LDS ring depth of the batch trace kernels (deep trees)
-#define RT_SEG_BLOCKS 1280      // persistent grid of every wavefront kernel == number of queue segments
+#define RT_SEG_BLOCKS 1024      // persistent grid of every wavefront kernel == number of queue segments
 #define RT_SEG_PER_THREAD (RT_SEG_BLOCKS / RT_BLOCK)
 
 // Queues are segmented: block b of a producer kernel appends only to segment b (positions
@@ -225,12 +225,12 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_trace_pairs(DevScene sc, size_t
         bool walk = L.mode == RT_LANE_WALK, leaf = L.mode == RT_LANE_LEAF;
         uint64_t lm = __ballot(leaf), wm = __ballot(walk);
         if (QUAD) {
-            if (__ballot(walk && !L.plain) == 0 && !exact_slabs) { if (walk) lane_walk_quad<true>(sc, L, st, info, have); }     // the whole wave takes one version
-            else if (walk) lane_walk_quad<false>(sc, L, st, info, have);
-        } else if (walk) lane_walk<COUNT>(sc, L, st, nNodes, info, have);
+            if (__ballot(walk && !L.plain) == 0 && !exact_slabs) { if (walk) lane_walk_quad<true>(sc.quads, L, st, info, have); }     // the whole wave takes one version
+            else if (walk) lane_walk_quad<false>(sc.quads, L, st, info, have);
+        } else if (walk) lane_walk<COUNT, false>(sc.pairs, L, st, nNodes, info, have);
         bool leafrun = leaf && (__popcll(lm) >= leaf_min || wm == 0);
         if (leafrun) {
-            LeafOut r = lane_leaf<ANY, COUNT>(sc, L, st, nTests);
+            LeafOut r = lane_leaf<ANY, COUNT>(sc, sc.slots, L, st, nTests);
             L.found = r.found; L.tmax = r.tmax; L.hitSlot = r.hitSlot; L.b0 = r.b0; L.b1 = r.b1; L.b2 = r.b2;
             info = r.info; have = r.have;
         }
@@ -703,6 +703,227 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, Sh
     }
 }
 
+// ------------------------------------------------ persistent-lane frame tracing --
+// k_extend / k_shadow above give every lane one ray per round and the wave waits for its slowest lane: on Cornell only a
+// third of the lanes are busy on average.  The kernels below walk the same queues with persistent lanes (rt_traverse2.h):
+// a lane that finishes its ray takes the next one of its wave's range at once.  Rays are staged through LDS a batch of 64
+// at a time (coalesced loads issued one batch ahead), so a refill never waits on global memory; results go out with plain
+// stores; everything that needs a global read-modify-write or a wave-wide append (emission, class binning, adding the
+// unoccluded light) runs afterwards as a second, coalesced sweep over the block's share.
+#define RT_FRAME_RING 8          // LDS ring entries per lane (node, tMin)
+#define RT_LDS_SCENE_PAIRS (RT_LDS_SCENE_NODES / 2)
+enum { RT_WALK_LDS_PAIRS = 0, RT_WALK_QUADS = 1, RT_WALK_PAIRS = 2 };
+
+struct RayArrays { const float *ox, *oy, *oz, *dx, *dy, *dz; };
+
+// Traverse the rays at concatenated positions [lo, hi) of a segmented queue; sink(i, L) receives each finished ray
+// (i = its position in the queue arrays).  recs = pair or quad records (LDS or global), slots = leaf slots.
+template <bool ANY, int MODE, class Sink>
+__device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *recs, const float4 *slots, RayArrays ra, float tmax0, uint32_t lo, uint32_t hi,
+                                            const uint32_t *s_prefix, uint32_t segcap, PairStackT<RT_FRAME_RING> &st, float *s_ray, int leaf_min, Sink sink) {
+    const uint32_t lane = lane_id(), wave = threadIdx.x / RT_WAVE;
+    const uint32_t per = (((hi - lo) + RT_BLOCK / RT_WAVE - 1) / (RT_BLOCK / RT_WAVE) + RT_WAVE - 1) & ~(uint32_t)(RT_WAVE - 1);
+    const uint32_t w_lo = lo + wave * per < hi ? lo + wave * per : hi, w_hi = w_lo + per < hi ? w_lo + per : hi;
+    uint32_t w_next = w_lo;
+    uint32_t seg = w_lo < w_hi ? segment_of(s_prefix, w_lo) : 0;      // per-lane cursor; a lane's positions only grow
+    float p_ox = 0.f, p_oy = 0.f, p_oz = 0.f, p_dx = 0.f, p_dy = 0.f, p_dz = 1.f; uint32_t p_i = 0;   // the batch being prefetched
+    uint32_t pf_count = 0;                                            // rays in the prefetch registers (wave-uniform)
+    auto prefetch = [&]() {
+        pf_count = w_hi - w_next < RT_WAVE ? w_hi - w_next : RT_WAVE;
+        if (lane < pf_count) {
+            uint32_t g = w_next + lane;
+            while (g >= s_prefix[seg + 1]) seg++;
+            p_i = seg * segcap + (g - s_prefix[seg]);
+            p_ox = ra.ox[p_i]; p_oy = ra.oy[p_i]; p_oz = ra.oz[p_i]; p_dx = ra.dx[p_i]; p_dy = ra.dy[p_i]; p_dz = ra.dz[p_i];
+        }
+        w_next += pf_count;
+    };
+    prefetch();
+    uint32_t avail = 0, rd = 0;                                       // rays left in the LDS batch, read cursor (wave-uniform)
+    LaneTrav L = {};
+    L.mode = RT_LANE_DONE; L.hitSlot = -1;
+    bool busy = false;                                                // the lane holds a ray (possibly finished, not yet handed to the sink)
+    uint32_t cur_i = 0, dummy = 0;
+    // Every lane is walking, waiting at a leaf, or idle (finished / never started).  Each round the wave runs ONE of the
+    // three phases, the one most lanes are waiting for, so the instructions of a phase are issued for a well-filled wave.
+    while (true) {
+        const bool walk = busy && L.mode == RT_LANE_WALK, leaf = busy && L.mode == RT_LANE_LEAF, idle = !busy || L.mode == RT_LANE_DONE;
+        const uint64_t im = __ballot(idle);
+        const uint32_t nW = (uint32_t)__popcll(__ballot(walk)), nL = (uint32_t)__popcll(__ballot(leaf));
+        const uint32_t supply = avail + pf_count, nIdle = (uint32_t)__popcll(im), nI = nIdle < supply ? nIdle : supply;
+        if (nW == 0 && nL == 0 && nI == 0) break;
+        uint32_t info = 0; bool have = false, moved = false;
+        if (nW >= nL && nW >= nI) {
+            if (MODE == RT_WALK_QUADS) {
+                if (__ballot(walk && !L.plain) == 0) { if (walk) lane_walk_quad<true>(recs, L, st, info, have); }     // the whole wave takes one version
+                else if (walk) lane_walk_quad<false>(recs, L, st, info, have);
+            } else {
+                if (__ballot(walk && !L.plain) == 0) { if (walk) lane_walk<false, true>(recs, L, st, dummy, info, have); }
+                else if (walk) lane_walk<false, false>(recs, L, st, dummy, info, have);
+            }
+            moved = walk;
+        } else if (nL >= nI) {
+            if (leaf) {
+                LeafOut r = lane_leaf<ANY, false>(sc, slots, L, st, dummy);
+                L.found = r.found; L.tmax = r.tmax; L.hitSlot = r.hitSlot; L.b0 = r.b0; L.b1 = r.b1; L.b2 = r.b2;
+                info = r.info; have = r.have;
+            }
+            moved = leaf;
+        } else {
+            if (busy && L.mode == RT_LANE_DONE) { sink(cur_i, L); busy = false; }
+            if (avail == 0) {                                         // LDS batch used up: the prefetched one becomes current (supply > 0 here)
+                if (lane < pf_count) {
+                    s_ray[lane] = p_ox; s_ray[RT_WAVE + lane] = p_oy; s_ray[2 * RT_WAVE + lane] = p_oz; s_ray[3 * RT_WAVE + lane] = p_dx;
+                    s_ray[4 * RT_WAVE + lane] = p_dy; s_ray[5 * RT_WAVE + lane] = p_dz; s_ray[6 * RT_WAVE + lane] = __uint_as_float(p_i);
+                }
+                avail = pf_count; rd = 0;
+                prefetch();
+            }
+            const uint32_t rank = prefix_in_mask(im), take = nIdle < avail ? nIdle : avail;
+            if (idle && rank < take) {
+                uint32_t k = rd + rank;
+                F3 po = f3(s_ray[k], s_ray[RT_WAVE + k], s_ray[2 * RT_WAVE + k]), pd = f3(s_ray[3 * RT_WAVE + k], s_ray[4 * RT_WAVE + k], s_ray[5 * RT_WAVE + k]);
+                cur_i = __float_as_uint(s_ray[6 * RT_WAVE + k]);
+                busy = true; moved = true;
+                have = lane_begin<false>(sc, L, st, po, pd, tmax0, dummy); info = sc.root_info;
+            }
+            rd += take; avail -= take;
+        }
+        if (moved) lane_enter(sc, L, info, have);
+    }
+    if (busy && L.mode == RT_LANE_DONE) sink(cur_i, L);
+}
+
+// Scene records for trace_share: an LDS copy of pair records and slots (small scenes), else quad or pair records in HBM.
+template <int MODE>
+__device__ __forceinline__ void stage_walk_scene(const DevScene &sc, float4 *s_pairs, float4 *s_slots, const float4 *&recs, const float4 *&slots) {
+    if (MODE == RT_WALK_LDS_PAIRS) {
+        for (int i = threadIdx.x; i < 4 * sc.n_pairs; i += RT_BLOCK) s_pairs[i] = sc.pairs[i];
+        for (int i = threadIdx.x; i < 3 * sc.n_slots; i += RT_BLOCK) s_slots[i] = sc.slots[i];
+        recs = s_pairs; slots = s_slots;
+    } else { recs = MODE == RT_WALK_QUADS ? sc.quads : sc.pairs; slots = sc.slots; }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(RT_BLOCK) void k_extend_pl(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
+                                                         uint32_t segcap, float4 *lbuf, BounceCounts *counts, BounceStats *stats, int *spill, int leaf_min) {
+    __shared__ int s_si[RT_FRAME_RING * RT_BLOCK];
+    __shared__ float s_st[RT_FRAME_RING * RT_BLOCK];
+    __shared__ float s_rays[(RT_BLOCK / RT_WAVE) * 7 * RT_WAVE];
+    __shared__ float4 s_pairs[MODE == RT_WALK_LDS_PAIRS ? 4 * RT_LDS_SCENE_PAIRS : 1], s_slots[MODE == RT_WALK_LDS_PAIRS ? 3 * RT_LDS_SCENE_SLOTS : 1];
+    __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE], s_cls[RT_NUM_CLASSES];
+    const float4 *recs, *slots;
+    stage_walk_scene<MODE>(sc, s_pairs, s_slots, recs, slots);
+    BounceCounts *bc = counts + bounce;
+    if (threadIdx.x < RT_NUM_CLASSES) s_cls[threadIdx.x] = 0;
+    const uint32_t total = segment_prefix(bc->queue, s_prefix, s_wave);      // its barriers also cover the staging above
+    uint32_t lo, hi;
+    block_share(total, lo, hi);
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_queue = total;
+    // the shading kernels of this bounce append to segment blockIdx.x of the shadow queue and of the next queue
+    if (threadIdx.x == 0) { bc->shadow[blockIdx.x] = 0; counts[bounce + 1].queue[blockIdx.x] = 0; }
+    size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    PairStackT<RT_FRAME_RING> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
+    st.cap = MODE == RT_WALK_QUADS ? sc.quad_stack_cap : RT_MAX_STACK;
+    st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
+    RayArrays ra = {q.ox, q.oy, q.oz, q.dx, q.dy, q.dz};
+    trace_share<false, MODE>(sc, recs, slots, ra, RT_INF, lo, hi, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE], leaf_min,
+                             [&](uint32_t i, const LaneTrav &L) {
+                                 hb.slot[i] = L.found ? L.hitSlot : -1; hb.t[i] = L.tmax; hb.b0[i] = L.b0; hb.b1[i] = L.b1; hb.b2[i] = L.b2;
+                             });
+    __threadfence_block();
+    __syncthreads();
+    // second sweep, coalesced: emission / sky / termination (integrator.cpp:242-257) and class binning
+    uint32_t seg = lo < hi ? segment_of(s_prefix, lo) : 0;
+    const uint32_t seg_base = blockIdx.x * segcap;
+    for (uint32_t base = lo; base < hi; base += RT_BLOCK) {
+        uint32_t g = base + threadIdx.x;
+        bool active = g < hi;
+        int cls = -1;
+        uint32_t i = 0;
+        if (active) {
+            while (g >= s_prefix[seg + 1]) seg++;
+            i = seg * segcap + (g - s_prefix[seg]);
+            int slot = hb.slot[i];
+            bool found = slot >= 0;
+            uint32_t state = q.state[i];
+            int depth = state & 0xFFFF; bool spec = (state >> 16) & 1;
+            F3 add = f3(0.f, 0.f, 0.f); bool terminal = false;
+            if (depth == 0 || spec || sc.n_lights == 0) {
+                if (found) {
+                    int li = sc.slot_light[slot];
+                    if (li >= 0) {
+                        F3 d = f3(q.dx[i], q.dy[i], q.dz[i]);
+                        const DevLight &Lt = sc.lights[li];
+                        float4 nf = sc.frames[3 * slot];
+                        if (Lt.two_sided || dot3(f3(nf.x, nf.y, nf.z), -d) > 0) add = f3(Lt.Le[0], Lt.Le[1], Lt.Le[2]);   // light.h:73-75
+                        if (!black3(add)) terminal = true;
+                    }
+                } else if (sc.n_lights == 0) {
+                    F3 ud = normalize3(f3(q.dx[i], q.dy[i], q.dz[i]));
+                    double t = 0.5 * (ud.y + 1.0);
+                    float a = (float)(1.0 - t), b = (float)t;
+                    add = f3(1.0f * a + 0.5f * b, 1.0f * a + 0.7f * b, 1.0f * a + 1.0f * b);
+                }
+            }
+            if (!found || depth >= rp.max_depth) terminal = true;
+            if (!black3(add)) {
+                uint32_t id = q.id[i];
+                float4 Lr = lbuf[id];
+                Lr.x += q.tr[i] * add.x; Lr.y += q.tg[i] * add.y; Lr.z += q.tb[i] * add.z;
+                lbuf[id] = Lr;
+            }
+            if (!terminal) cls = sc.materials[sc.slot_material[slot]].kind;
+        }
+        for (int c = 0; c < RT_NUM_CLASSES; ++c) {
+            bool mine = (cls == c);
+            if (__ballot(mine) == 0) continue;
+            uint32_t pos = block_append(mine, &s_cls[c]);
+            if (mine) cls_list[(size_t)c * cap + seg_base + pos] = i;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < RT_NUM_CLASSES) bc->cls[threadIdx.x][blockIdx.x] = s_cls[threadIdx.x];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow_pl(DevScene sc, int bounce, ShadowQueue sq, int *occluded, uint32_t segcap, float4 *lbuf, BounceCounts *counts,
+                                                         BounceStats *stats, int *spill, int leaf_min) {
+    __shared__ int s_si[RT_FRAME_RING * RT_BLOCK];
+    __shared__ float s_st[RT_FRAME_RING * RT_BLOCK];
+    __shared__ float s_rays[(RT_BLOCK / RT_WAVE) * 7 * RT_WAVE];
+    __shared__ float4 s_pairs[MODE == RT_WALK_LDS_PAIRS ? 4 * RT_LDS_SCENE_PAIRS : 1], s_slots[MODE == RT_WALK_LDS_PAIRS ? 3 * RT_LDS_SCENE_SLOTS : 1];
+    __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE];
+    const float4 *recs, *slots;
+    stage_walk_scene<MODE>(sc, s_pairs, s_slots, recs, slots);
+    BounceCounts *bc = counts + bounce;
+    const uint32_t total = segment_prefix(bc->shadow, s_prefix, s_wave);
+    uint32_t lo, hi;
+    block_share(total, lo, hi);
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_shadow = total;
+    size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    PairStackT<RT_FRAME_RING> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
+    st.cap = MODE == RT_WALK_QUADS ? sc.quad_stack_cap : RT_MAX_STACK;
+    st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
+    RayArrays ra = {sq.ox, sq.oy, sq.oz, sq.dx, sq.dy, sq.dz};
+    // tMax = 1 - ShadowEpsilon (interaction.h SpawnRayTo)
+    trace_share<true, MODE>(sc, recs, slots, ra, 1.f - 0.0001f, lo, hi, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE], leaf_min,
+                            [&](uint32_t i, const LaneTrav &L) { occluded[i] = L.found ? 1 : 0; });
+    __threadfence_block();
+    __syncthreads();
+    uint32_t seg = lo < hi ? segment_of(s_prefix, lo) : 0;
+    for (uint32_t g = lo + threadIdx.x; g < hi; g += RT_BLOCK) {
+        while (g >= s_prefix[seg + 1]) seg++;
+        uint32_t i = seg * segcap + (g - s_prefix[seg]);
+        if (!occluded[i]) {
+            uint32_t id = sq.id[i];
+            float4 Lr = lbuf[id];
+            Lr.x += sq.cr[i]; Lr.y += sq.cg[i]; Lr.z += sq.cb[i];
+            lbuf[id] = Lr;
+        }
+    }
+}
+
 // -------------------------------------------------------------- accumulate --
 __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const float4 *lbuf, int spb, uint32_t npix, float *sum_rgb) {
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
@@ -1163,7 +1384,15 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     size_t npix = (size_t)W * H;
     if (npix > (1u << 30)) { set_error(ctx, "rt_render: image too large"); return -1; }
     int S = o->sample_end - o->sample_begin;
-    size_t pool = o->pool_paths > 0 ? (size_t)o->pool_paths : ((size_t)16 << 20);
+    // Paths per pass.  Every pass ends in a tail of near-empty bounces whose cost is fixed, so passes should be few and large:
+    // 188 bytes of queue state per path, 256 Mi paths = 50 GB of the 288 GB; never more than a third of what is free.
+    size_t pool = (size_t)o->pool_paths;
+    if (o->pool_paths <= 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_OK(hipMemGetInfo(&free_b, &total_b));
+        free_b += this_->ws_cap * 188;                       // the workspace of an earlier call is reused
+        pool = std::min<size_t>((size_t)256 << 20, std::max<size_t>((size_t)1 << 20, free_b / 3 / 188));
+    }
     int spb = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(S, 1), pool / npix));
     size_t n_pass = npix * (size_t)spb;
     if (n_pass >= (1ull << 31)) { set_error(ctx, "rt_render: pass too large"); return -1; }
@@ -1209,6 +1438,9 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     const uint32_t ucap = (uint32_t)wcap, useg = (uint32_t)segcap;
     // scenes small enough are traversed out of an LDS copy (no spheres: their records stay in global memory)
     const bool lds_scene = this_->dev.n_nodes <= RT_LDS_SCENE_NODES && this_->dev.n_slots <= RT_LDS_SCENE_SLOTS;
+    const bool frame_old = env_int("RT_AMD_FRAME_NODE_WALK", 0) != 0;       // knob: the one-ray-per-lane-per-round kernels
+    const int walk_mode = lds_scene ? RT_WALK_LDS_PAIRS : (this_->dev.quads ? RT_WALK_QUADS : RT_WALK_PAIRS);
+    const int frame_leaf_min = std::max(1, std::min(64, env_int("RT_AMD_FRAME_LEAF_MIN", 16)));
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
         int cur = std::min(spb, o->sample_end - s0);
         rp.spb = cur; rp.sample0 = s0; rp.n_paths = (uint32_t)(npix * (size_t)cur);
@@ -1216,12 +1448,22 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
         hipLaunchKernelGGL(k_raygen, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, rp, q[0], useg, lbuf, counts);
         int cq = 0;
         for (int b = 0; b <= o->max_depth; ++b) {
-            if (lds_scene)
-                hipLaunchKernelGGL(k_extend<true>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p, ucap,
-                                   useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
+            if (frame_old) {
+                if (lds_scene)
+                    hipLaunchKernelGGL(k_extend<true>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
+                                       ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
+                else
+                    hipLaunchKernelGGL(k_extend<false>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
+                                       ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
+            } else if (walk_mode == RT_WALK_LDS_PAIRS)
+                hipLaunchKernelGGL(k_extend_pl<RT_WALK_LDS_PAIRS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
+                                   (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, frame_leaf_min);
+            else if (walk_mode == RT_WALK_QUADS)
+                hipLaunchKernelGGL(k_extend_pl<RT_WALK_QUADS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
+                                   (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, frame_leaf_min);
             else
-                hipLaunchKernelGGL(k_extend<false>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p, ucap,
-                                   useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
+                hipLaunchKernelGGL(k_extend_pl<RT_WALK_PAIRS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
+                                   (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, frame_leaf_min);
             if (b < o->max_depth) {
                 if (this_->classes[RT_MAT_MATTE]) launch_shade<RT_MAT_MATTE>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->classes[RT_MAT_MIRROR]) launch_shade<RT_MAT_MIRROR>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
@@ -1229,12 +1471,22 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                 if (this_->classes[RT_MAT_METAL]) launch_shade<RT_MAT_METAL>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->dev.n_lights > 0) {
-                    if (lds_scene)
-                        hipLaunchKernelGGL(k_shadow<true>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
-                                           (int *)this_->d_spill.p);
+                    if (frame_old) {
+                        if (lds_scene)
+                            hipLaunchKernelGGL(k_shadow<true>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
+                                               (int *)this_->d_spill.p);
+                        else
+                            hipLaunchKernelGGL(k_shadow<false>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
+                                               (int *)this_->d_spill.p);
+                    } else if (walk_mode == RT_WALK_LDS_PAIRS)       // the hit buffer's slot array is free once the shading kernels are done
+                        hipLaunchKernelGGL(k_shadow_pl<RT_WALK_LDS_PAIRS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, hb.slot, useg, lbuf,
+                                           counts, bstats, (int *)this_->d_spill.p, frame_leaf_min);
+                    else if (walk_mode == RT_WALK_QUADS)
+                        hipLaunchKernelGGL(k_shadow_pl<RT_WALK_QUADS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, hb.slot, useg, lbuf,
+                                           counts, bstats, (int *)this_->d_spill.p, frame_leaf_min);
                     else
-                        hipLaunchKernelGGL(k_shadow<false>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
-                                           (int *)this_->d_spill.p);
+                        hipLaunchKernelGGL(k_shadow_pl<RT_WALK_PAIRS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, hb.slot, useg, lbuf,
+                                           counts, bstats, (int *)this_->d_spill.p, frame_leaf_min);
                 }
             }
             cq ^= 1;

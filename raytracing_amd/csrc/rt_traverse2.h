@@ -165,16 +165,22 @@ __device__ __forceinline__ bool lane_begin(const DevScene &sc, LaneTrav &L, Stac
 }
 // One interior step: both children of pair node L.cur.  Hands back the info word of the node to enter next (have = false:
 // the ray is finished).
-template <bool COUNT, class Stack>
-__device__ __forceinline__ void lane_walk(const DevScene &sc, const LaneTrav &L, Stack &st, uint32_t &nNodes, uint32_t &info, bool &have) {
-    const float4 *P = sc.pairs + 4 * (size_t)L.cur;
+template <bool COUNT, bool PLAIN, class Stack>
+__device__ __forceinline__ void lane_walk(const float4 *pairs, const LaneTrav &L, Stack &st, uint32_t &nNodes, uint32_t &info, bool &have) {
+    const float4 *P = pairs + 4 * (size_t)L.cur;
     float4 q0 = P[0], q1 = P[1], q2 = P[2], q3 = P[3];
     uint32_t infoL = __float_as_uint(q3.x), infoR = __float_as_uint(q3.y);
     int axis = __float_as_int(q3.z);
     bool neg = ((L.sign >> axis) & 1u) != 0;
     float tL, tR;
-    bool okL = slab_partial(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, L.o, L.invDir, L.negx, L.negy, L.negz, tL);
-    bool okR = slab_partial(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, L.o, L.invDir, L.negx, L.negy, L.negz, tR);
+    bool okL, okR;
+    if (PLAIN) {
+        okL = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, L.o, L.invDir, tL);
+        okR = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, L.o, L.invDir, tR);
+    } else {
+        okL = slab_partial(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, L.o, L.invDir, L.negx, L.negy, L.negz, tL);
+        okR = slab_partial(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, L.o, L.invDir, L.negx, L.negy, L.negz, tR);
+    }
     if (COUNT) nNodes += 2;
     // bvh.cpp:266-273: negative direction along the split axis visits the second child first
     bool okN = neg ? okR : okL, okF = neg ? okL : okR;
@@ -237,8 +243,8 @@ __device__ __forceinline__ void quad_side(const LaneTrav &L, float a0, float a1,
 
 // One interior step over quad node L.cur: the node's two children and four grandchildren.
 template <bool PLAIN, class Stack>
-__device__ __forceinline__ void lane_walk_quad(const DevScene &sc, const LaneTrav &L, Stack &st, uint32_t &info, bool &have) {
-    const float4 *Q = sc.quads + 8 * (size_t)L.cur;
+__device__ __forceinline__ void lane_walk_quad(const float4 *quads, const LaneTrav &L, Stack &st, uint32_t &info, bool &have) {
+    const float4 *Q = quads + 8 * (size_t)L.cur;
     float4 q0 = Q[0], q1 = Q[1], q2 = Q[2], q3 = Q[3], q4 = Q[4], q5 = Q[5], q6 = Q[6];
     uint32_t meta = ((const uint32_t *)Q)[28];
     QuadCand l0, l1, r0, r1;
@@ -265,12 +271,12 @@ __device__ __forceinline__ void lane_walk_quad(const DevScene &sc, const LaneTra
 // Test the primitives of the pending leaf (bvh.cpp:258-261 / 294-299) and pick the next node.
 struct LeafOut { bool found; float tmax; int hitSlot; float b0, b1, b2; uint32_t info; bool have; };
 template <bool ANY, bool COUNT, class Stack>
-__device__ __forceinline__ LeafOut lane_leaf(const DevScene &sc, const LaneTrav &L, Stack &st, uint32_t &nTests) {
+__device__ __forceinline__ LeafOut lane_leaf(const DevScene &sc, const float4 *slots, const LaneTrav &L, Stack &st, uint32_t &nTests) {
     LeafOut r; r.found = L.found; r.tmax = L.tmax; r.hitSlot = L.hitSlot; r.b0 = L.b0; r.b1 = L.b1; r.b2 = L.b2;
     bool stop = false;
     for (int i = 0; i < L.count && !stop; ++i) {
         int slot = L.cur + i;
-        float4 r0 = sc.slots[3 * (size_t)slot], r1 = sc.slots[3 * (size_t)slot + 1], r2 = sc.slots[3 * (size_t)slot + 2];
+        float4 r0 = slots[3 * (size_t)slot], r1 = slots[3 * (size_t)slot + 1], r2 = slots[3 * (size_t)slot + 2];
         uint32_t flags = __float_as_uint(r2.y);
         if (COUNT) nTests++;
         float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
