@@ -138,17 +138,28 @@ __device__ __forceinline__ bool slab_test(float4 n0, float4 n1, F3 o, F3 invDir,
 __device__ __forceinline__ float pick3(F3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
 
 // Triangle::Intersect / IntersectP up to the `t <= eps` test, triangle.cpp:52-119.
-__device__ __forceinline__ bool triangle_test(F3 p0, F3 p1, F3 p2, F3 o, F3 dir, float rayTMax, float &t, float &b0, float &b1, float &b2) {
-    F3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
+// The permutation (kz = largest |d| component) and the shear constants depend on the ray alone (triangle.cpp:62-72);
+// ray_shear computes them once per ray and triangle_test_sheared uses them, with the same operations in the same order.
+struct RayShear { int kz; float Sx, Sy, Sz; };
+__device__ __forceinline__ RayShear ray_shear(F3 dir) {
     float ax = fabsf(dir.x), ay = fabsf(dir.y), az = fabsf(dir.z);
-    int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+    RayShear r;
+    r.kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+    int kx = r.kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    float dx = pick3(dir, kx), dy = pick3(dir, ky), dz = pick3(dir, r.kz);
+    r.Sx = -dx / dz; r.Sy = -dy / dz; r.Sz = 1.f / dz;
+    return r;
+}
+__device__ __forceinline__ bool triangle_test_sheared(F3 p0, F3 p1, F3 p2, F3 o, const RayShear &sh, float rayTMax, float &t, float &b0, float &b1, float &b2) {
+    F3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
+    int kz = sh.kz;
     int kx = kz + 1; if (kx == 3) kx = 0;
     int ky = kx + 1; if (ky == 3) ky = 0;
-    float dx = pick3(dir, kx), dy = pick3(dir, ky), dz = pick3(dir, kz);
     float p0x = pick3(p0t, kx), p0y = pick3(p0t, ky), p0z = pick3(p0t, kz);
     float p1x = pick3(p1t, kx), p1y = pick3(p1t, ky), p1z = pick3(p1t, kz);
     float p2x = pick3(p2t, kx), p2y = pick3(p2t, ky), p2z = pick3(p2t, kz);
-    float Sx = -dx / dz, Sy = -dy / dz, Sz = 1.f / dz;
+    float Sx = sh.Sx, Sy = sh.Sy, Sz = sh.Sz;
     p0x += Sx * p0z; p0y += Sy * p0z;
     p1x += Sx * p1z; p1y += Sy * p1z;
     p2x += Sx * p2z; p2y += Sy * p2z;
@@ -175,6 +186,10 @@ __device__ __forceinline__ bool triangle_test(F3 p0, F3 p1, F3 p2, F3 o, F3 dir,
     t = tScaled * invDet;
     if (t <= 1e-4f) return false;
     return true;
+}
+__device__ __forceinline__ bool triangle_test(F3 p0, F3 p1, F3 p2, F3 o, F3 dir, float rayTMax, float &t, float &b0, float &b1, float &b2) {
+    RayShear sh = ray_shear(dir);
+    return triangle_test_sheared(p0, p1, p2, o, sh, rayTMax, t, b0, b1, b2);
 }
 
 // Affine point / vector transforms by a 3x4 row-major matrix (Transform::operator(), transform.h:135-153;

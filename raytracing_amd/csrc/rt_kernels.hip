@@ -718,9 +718,9 @@ struct RayArrays { const float *ox, *oy, *oz, *dx, *dy, *dz; };
 
 // Traverse the rays at concatenated positions [lo, hi) of a segmented queue; sink(i, L) receives each finished ray
 // (i = its position in the queue arrays).  recs = pair or quad records (LDS or global), slots = leaf slots.
-template <bool ANY, int MODE, class Sink>
+template <bool ANY, int MODE, class Stack, class Sink>
 __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *recs, const float4 *slots, RayArrays ra, float tmax0, uint32_t lo, uint32_t hi,
-                                            const uint32_t *s_prefix, uint32_t segcap, PairStackT<RT_FRAME_RING> &st, float *s_ray, int leaf_min, Sink sink) {
+                                            const uint32_t *s_prefix, uint32_t segcap, Stack &st, float *s_ray, int leaf_min, Sink sink) {
     const uint32_t lane = lane_id(), wave = threadIdx.x / RT_WAVE;
     const uint32_t per = (((hi - lo) + RT_BLOCK / RT_WAVE - 1) / (RT_BLOCK / RT_WAVE) + RT_WAVE - 1) & ~(uint32_t)(RT_WAVE - 1);
     const uint32_t w_lo = lo + wave * per < hi ? lo + wave * per : hi, w_hi = w_lo + per < hi ? w_lo + per : hi;
@@ -758,8 +758,9 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
                 if (__ballot(walk && !L.plain) == 0) { if (walk) lane_walk_quad<true>(recs, L, st, info, have); }     // the whole wave takes one version
                 else if (walk) lane_walk_quad<false>(recs, L, st, info, have);
             } else {
-                if (__ballot(walk && !L.plain) == 0) { if (walk) lane_walk<false, true>(recs, L, st, dummy, info, have); }
-                else if (walk) lane_walk<false, false>(recs, L, st, dummy, info, have);
+                constexpr int KS = MODE == RT_WALK_LDS_PAIRS ? RT_LDS_SCENE_PAIRS : 1;
+                if (__ballot(walk && !L.plain) == 0) { if (walk) lane_walk<false, true, KS>(recs, L, st, dummy, info, have); }
+                else if (walk) lane_walk<false, false, KS>(recs, L, st, dummy, info, have);
             }
             moved = walk;
         } else if (nL >= nI) {
@@ -770,7 +771,7 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
             }
             moved = leaf;
         } else {
-            if (busy && L.mode == RT_LANE_DONE) { sink(cur_i, L); busy = false; }
+            // (the batch switch comes before the result stores so that its wait on the prefetched loads does not also wait on them)
             if (avail == 0) {                                         // LDS batch used up: the prefetched one becomes current (supply > 0 here)
                 if (lane < pf_count) {
                     s_ray[lane] = p_ox; s_ray[RT_WAVE + lane] = p_oy; s_ray[2 * RT_WAVE + lane] = p_oz; s_ray[3 * RT_WAVE + lane] = p_dx;
@@ -779,6 +780,7 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
                 avail = pf_count; rd = 0;
                 prefetch();
             }
+            if (busy && L.mode == RT_LANE_DONE) { sink(cur_i, L); busy = false; }
             const uint32_t rank = prefix_in_mask(im), take = nIdle < avail ? nIdle : avail;
             if (idle && rank < take) {
                 uint32_t k = rd + rank;
@@ -798,7 +800,7 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
 template <int MODE>
 __device__ __forceinline__ void stage_walk_scene(const DevScene &sc, float4 *s_pairs, float4 *s_slots, const float4 *&recs, const float4 *&slots) {
     if (MODE == RT_WALK_LDS_PAIRS) {
-        for (int i = threadIdx.x; i < 4 * sc.n_pairs; i += RT_BLOCK) s_pairs[i] = sc.pairs[i];
+        for (int i = threadIdx.x; i < 4 * sc.n_pairs; i += RT_BLOCK) s_pairs[(i & 3) * RT_LDS_SCENE_PAIRS + (i >> 2)] = sc.pairs[i];
         for (int i = threadIdx.x; i < 3 * sc.n_slots; i += RT_BLOCK) s_slots[i] = sc.slots[i];
         recs = s_pairs; slots = s_slots;
     } else { recs = MODE == RT_WALK_QUADS ? sc.quads : sc.pairs; slots = sc.slots; }
@@ -823,7 +825,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_pl(DevScene sc, RenderParam
     // the shading kernels of this bounce append to segment blockIdx.x of the shadow queue and of the next queue
     if (threadIdx.x == 0) { bc->shadow[blockIdx.x] = 0; counts[bounce + 1].queue[blockIdx.x] = 0; }
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    PairStackT<RT_FRAME_RING> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
+    PairStackT<RT_FRAME_RING, MODE != RT_WALK_LDS_PAIRS> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
     st.cap = MODE == RT_WALK_QUADS ? sc.quad_stack_cap : RT_MAX_STACK;
     st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     RayArrays ra = {q.ox, q.oy, q.oz, q.dx, q.dy, q.dz};
@@ -902,7 +904,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_pl(DevScene sc, int bounce,
     block_share(total, lo, hi);
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_shadow = total;
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    PairStackT<RT_FRAME_RING> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
+    PairStackT<RT_FRAME_RING, MODE != RT_WALK_LDS_PAIRS> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
     st.cap = MODE == RT_WALK_QUADS ? sc.quad_stack_cap : RT_MAX_STACK;
     st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     RayArrays ra = {sq.ox, sq.oy, sq.oz, sq.dx, sq.dy, sq.dz};
@@ -957,6 +959,7 @@ struct rt_scene {
     int n_prims = 0;
     bool classes[RT_NUM_CLASSES] = {false, false, false, false, false, false};
     DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_spill, d_pairs, d_quads;
+    int interior_depth = 0;
     std::vector<DevBuf *> d_texels;
     // render workspace
     DevBuf d_q[2], d_hits, d_cls, d_shadow, d_lbuf, d_counters, d_sum, d_trace_io, d_work;
@@ -1183,6 +1186,17 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     // quad nodes: one 128-byte record per even-depth interior node with the boxes of its four grandchildren.  Only for trees
     // whose interior boxes are bit for bit the min/max of their children's (true of every tree rt_bvh_build makes).
     std::vector<float> quads;
+    {   // interior levels of the tree = most entries a pair stack can hold at once
+        std::vector<std::pair<int, int>> todo; todo.push_back({0, 1});
+        int deepest = 0;
+        while (!todo.empty()) {
+            auto [node, level] = todo.back(); todo.pop_back();
+            if (sc->nodes[node].nprim != 0) continue;
+            deepest = std::max(deepest, level);
+            todo.push_back({node + 1, level + 1}); todo.push_back({sc->nodes[node].offset, level + 1});
+        }
+        sc->interior_depth = deepest;
+    }
     int n_quads = 0, tree_depth = 0;
     bool quads_ok = sc->nodes[0].nprim == 0;
     if (quads_ok) {
@@ -1437,9 +1451,12 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     std::vector<BounceStats> hs(n_bounce);
     const uint32_t ucap = (uint32_t)wcap, useg = (uint32_t)segcap;
     // scenes small enough are traversed out of an LDS copy (no spheres: their records stay in global memory)
-    const bool lds_scene = this_->dev.n_nodes <= RT_LDS_SCENE_NODES && this_->dev.n_slots <= RT_LDS_SCENE_SLOTS;
+    const bool lds_scene = this_->dev.n_nodes <= RT_LDS_SCENE_NODES && this_->dev.n_slots <= RT_LDS_SCENE_SLOTS && this_->interior_depth <= RT_FRAME_RING;
     const bool frame_old = env_int("RT_AMD_FRAME_NODE_WALK", 0) != 0;       // knob: the one-ray-per-lane-per-round kernels
     const int walk_mode = lds_scene ? RT_WALK_LDS_PAIRS : (this_->dev.quads ? RT_WALK_QUADS : RT_WALK_PAIRS);
+    // camera rays (and the shadow rays they spawn) are coherent: every lane of a wave finishes at about the same step, and
+    // the one-ray-per-lane-per-round kernels, which have no scheduling overhead, are faster for them on LDS-resident scenes
+    const int round_bounces = env_int("RT_AMD_FRAME_ROUND_BOUNCES", 2);
     const int frame_leaf_min = std::max(1, std::min(64, env_int("RT_AMD_FRAME_LEAF_MIN", 16)));
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
         int cur = std::min(spb, o->sample_end - s0);
@@ -1448,7 +1465,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
         hipLaunchKernelGGL(k_raygen, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, rp, q[0], useg, lbuf, counts);
         int cq = 0;
         for (int b = 0; b <= o->max_depth; ++b) {
-            if (frame_old) {
+            if (frame_old || (lds_scene && b < round_bounces)) {
                 if (lds_scene)
                     hipLaunchKernelGGL(k_extend<true>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
                                        ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
@@ -1471,7 +1488,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                 if (this_->classes[RT_MAT_METAL]) launch_shade<RT_MAT_METAL>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->dev.n_lights > 0) {
-                    if (frame_old) {
+                    if (frame_old || (lds_scene && b < round_bounces)) {
                         if (lds_scene)
                             hipLaunchKernelGGL(k_shadow<true>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
                                                (int *)this_->d_spill.p);

@@ -29,7 +29,9 @@
 #define RT_PAIR_STACK 16                // LDS ring entries per lane (index + tMin), pair kernels
 #define RT_QUAD_STACK 8                 // same, quad kernels (half the levels; a smaller ring lets more blocks share a CU)
 
-template <int RING>
+// SPILL = false: the caller guarantees that no more than RING entries are ever live (the tree is at most RING interior levels
+// deep), and the stack never touches global memory — which also keeps vector-memory waits out of the loops that use it.
+template <int RING, bool SPILL = true>
 struct PairStackT {
     int *lds_i; float *lds_t;       // &shared[0][threadIdx.x], stride RT_BLOCK
     int *spill_i; float *spill_t;   // &spill[0][global thread], stride spill_stride
@@ -38,7 +40,7 @@ struct PairStackT {
     int sp, lo;                     // entries [lo, sp) are in the ring
     __device__ __forceinline__ void reset() { sp = 0; lo = 0; }
     __device__ __forceinline__ void push(int info, float t) {
-        if (sp - lo == RING) {
+        if (SPILL && sp - lo == RING) {
             if (lo < cap) {
                 int k = (lo & (RING - 1)) * RT_BLOCK;
                 spill_i[(size_t)lo * spill_stride] = lds_i[k]; spill_t[(size_t)lo * spill_stride] = lds_t[k];
@@ -51,7 +53,7 @@ struct PairStackT {
     }
     __device__ __forceinline__ void pop(int &info, float &t) {
         sp--;
-        if (sp < lo) {
+        if (SPILL && sp < lo) {
             lo = sp;
             if (sp < cap) { info = spill_i[(size_t)sp * spill_stride]; t = spill_t[(size_t)sp * spill_stride]; }
             else { info = 0; t = RT_INF; }
@@ -114,6 +116,7 @@ struct LaneTrav {
     int cur, count;
     int hitSlot; float b0, b1, b2;
     bool found;
+    RayShear shear;      // per-ray constants of the triangle test
 };
 
 enum { RT_LANE_WALK = 0, RT_LANE_LEAF = 1, RT_LANE_DONE = 2 };
@@ -153,6 +156,7 @@ __device__ __forceinline__ bool lane_begin(const DevScene &sc, LaneTrav &L, Stac
     L.plain = finite_nonzero(L.invDir.x) && finite_nonzero(L.invDir.y) && finite_nonzero(L.invDir.z) && fabsf(o.x) < RT_INF && fabsf(o.y) < RT_INF &&
               fabsf(o.z) < RT_INF;
     L.hitSlot = -1; L.b0 = L.b1 = L.b2 = 0.f; L.found = false;
+    L.shear = ray_shear(d);
     st.reset();
     bool have = false;
     if (sc.n_nodes != 0) {
@@ -165,10 +169,12 @@ __device__ __forceinline__ bool lane_begin(const DevScene &sc, LaneTrav &L, Stac
 }
 // One interior step: both children of pair node L.cur.  Hands back the info word of the node to enter next (have = false:
 // the ray is finished).
-template <bool COUNT, bool PLAIN, class Stack>
+// KSTRIDE = 1: records stored one after the other (4 float4 each).  KSTRIDE = n: the k-th float4 of record r is at
+// pairs[k * n + r] — the layout of the LDS copy, where consecutive records then fall into different banks.
+template <bool COUNT, bool PLAIN, int KSTRIDE = 1, class Stack>
 __device__ __forceinline__ void lane_walk(const float4 *pairs, const LaneTrav &L, Stack &st, uint32_t &nNodes, uint32_t &info, bool &have) {
-    const float4 *P = pairs + 4 * (size_t)L.cur;
-    float4 q0 = P[0], q1 = P[1], q2 = P[2], q3 = P[3];
+    const float4 *P = pairs + (KSTRIDE == 1 ? 4 : 1) * (size_t)L.cur;
+    float4 q0 = P[0], q1 = P[KSTRIDE], q2 = P[2 * KSTRIDE], q3 = P[3 * KSTRIDE];
     uint32_t infoL = __float_as_uint(q3.x), infoR = __float_as_uint(q3.y);
     int axis = __float_as_int(q3.z);
     bool neg = ((L.sign >> axis) & 1u) != 0;
@@ -283,7 +289,7 @@ __device__ __forceinline__ LeafOut lane_leaf(const DevScene &sc, const float4 *s
         bool ok;
         if (flags & RT_SLOT_SPHERE) ok = sphere_test(sc.spheres + 32 * (size_t)__float_as_int(r2.w), L.o, L.d, r.tmax, t);
         else {
-            ok = triangle_test(f3(r0.x, r0.y, r0.z), f3(r0.w, r1.x, r1.y), f3(r1.z, r1.w, r2.x), L.o, L.d, r.tmax, t, b0, b1, b2);
+            ok = triangle_test_sheared(f3(r0.x, r0.y, r0.z), f3(r0.w, r1.x, r1.y), f3(r1.z, r1.w, r2.x), L.o, L.shear, r.tmax, t, b0, b1, b2);
             if (!ANY && (flags & RT_SLOT_REJECT_CLOSEST)) ok = false;
         }
         if (ok) {
