@@ -1454,8 +1454,9 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     const bool lds_scene = this_->dev.n_nodes <= RT_LDS_SCENE_NODES && this_->dev.n_slots <= RT_LDS_SCENE_SLOTS && this_->interior_depth <= RT_FRAME_RING;
     const bool frame_old = env_int("RT_AMD_FRAME_NODE_WALK", 0) != 0;       // knob: the one-ray-per-lane-per-round kernels
     const int walk_mode = lds_scene ? RT_WALK_LDS_PAIRS : (this_->dev.quads ? RT_WALK_QUADS : RT_WALK_PAIRS);
-    // camera rays (and the shadow rays they spawn) are coherent: every lane of a wave finishes at about the same step, and
-    // the one-ray-per-lane-per-round kernels, which have no scheduling overhead, are faster for them on LDS-resident scenes
+    // On LDS-resident scenes the first bounces, whose rays are the most coherent (lanes of a wave finish at about the same
+    // step), run faster through the one-ray-per-lane-per-round kernels, which have no scheduling overhead (measured on
+    // Cornell: 943 / 978 / 985 / 974 Msamples/s for 0 / 1 / 2 / 3 such bounces)
     const int round_bounces = env_int("RT_AMD_FRAME_ROUND_BOUNCES", 2);
     const int frame_leaf_min = std::max(1, std::min(64, env_int("RT_AMD_FRAME_LEAF_MIN", 16)));
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
