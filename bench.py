@@ -34,8 +34,38 @@ MAX_DEPTH = 50        # RayTracing.cpp:431
 HBM_PEAK_GBS = 8000.0
 
 
-def traversal_roofline(ctx, n_tris, n_rays, repeats):
-    """Closest-hit traversal of incoherent rays through the N-triangle soup; rays resident in HBM (SoA)."""
+def _next_bounce_rays(rays, hits, tri_p, gen):
+    """Cosine-hemisphere rays off the geometric normal of every hit (the soup workload's bounces): origin offset as
+    OffsetRayOrigin (geometry.h:916-923), normal = normalize(cross(p0-p2, p1-p2)) (triangle.cpp:146) turned towards the
+    incoming ray.  Misses drop out.  Pure torch: this only PRODUCES the next batch, it is not part of the timed kernel."""
+    prim = hits[0].view(torch.int32)
+    keep = (prim >= 0).nonzero(as_tuple=True)[0]
+    if keep.numel() == 0:
+        return None
+    o = rays[0:3, keep]; d = rays[3:6, keep]; t = hits[1, keep]
+    P = tri_p[prim[keep].long()]                                   # (m, 3, 3)
+    n = torch.cross(P[:, 0] - P[:, 2], P[:, 1] - P[:, 2], dim=1)
+    n = (n / n.norm(dim=1, keepdim=True)).t()                      # (3, m)
+    flip = (n * d).sum(0) > 0
+    nf = torch.where(flip, -n, n)
+    p = o + t * d
+    u1 = torch.rand(keep.numel(), generator=gen, device=rays.device); u2 = torch.rand(keep.numel(), generator=gen, device=rays.device)
+    r = u1.sqrt(); phi = 2 * np.pi * u2
+    lx, ly, lz = r * phi.cos(), r * phi.sin(), (1 - u1).clamp_min(0).sqrt()
+    a = torch.where(nf[0].abs() > 0.9, torch.tensor([0.0, 1.0, 0.0], device=rays.device)[:, None], torch.tensor([1.0, 0.0, 0.0], device=rays.device)[:, None])
+    s_ = torch.cross(nf.t(), a.t(), dim=1).t(); s_ = s_ / s_.norm(dim=0, keepdim=True)
+    tt = torch.cross(nf.t(), s_.t(), dim=1).t()
+    w = lx * s_ + ly * tt + lz * nf
+    off = nf * (1e-4 * nf.abs().sum(0))
+    no = p + off                                                   # w lies on nf's side by construction
+    tmax = torch.full((1, keep.numel()), float("inf"), device=rays.device)
+    return torch.cat([no, w, tmax], dim=0).contiguous()
+
+
+def traversal_roofline(ctx, n_tris, n_rays, repeats, bounces=4):
+    """Closest-hit traversal of incoherent rays through the N-triangle soup; rays resident in HBM (SoA).  The headline
+    figure is the first batch (uniform origins and directions); `bounce_batches` follows the rays through up to four
+    cosine-hemisphere bounces."""
     scene = ra.HostScene("soup", n_tris)
     ds = ra.DeviceScene(ctx, scene.desc_ptr)
     g = torch.Generator(device="cuda"); g.manual_seed(1234)
@@ -43,14 +73,21 @@ def traversal_roofline(ctx, n_tris, n_rays, repeats):
     d = torch.randn((3, n_rays), generator=g, device="cuda"); d = d / d.norm(dim=0, keepdim=True)
     tmax = torch.full((1, n_rays), float("inf"), device="cuda")
     rays = torch.cat([o, d, tmax], dim=0).contiguous()
-    hits = torch.empty((4, n_rays), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
-    st = ds.trace_closest_device(n_rays, rays.data_ptr(), hits.data_ptr(), repeats=1, count_work=True)     # counts + warm-up
-    nodes, tests = st.nodes_visited, st.prims_tested
-    st = ds.trace_closest_device(n_rays, rays.data_ptr(), hits.data_ptr(), repeats=repeats)
-    # algorithmic bytes: 32 B per node slab-tested + 36 B per triangle tested + 32 B ray in + 16 B hit out
-    bytes_per_launch = 32.0 * nodes + 36.0 * tests + 48.0 * n_rays
-    achieved = bytes_per_launch / st.seconds / 1e9
+    del o, d, tmax
+
+    def measure(rays, reps):
+        n = rays.shape[1]
+        hits = torch.empty((4, n), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        st = ds.trace_closest_device(n, rays.data_ptr(), hits.data_ptr(), repeats=1, count_work=True)     # counts + warm-up
+        nodes, tests = st.nodes_visited, st.prims_tested
+        st = ds.trace_closest_device(n, rays.data_ptr(), hits.data_ptr(), repeats=reps)
+        # algorithmic bytes: 32 B per node slab-tested + 36 B per triangle tested + 32 B ray in + 16 B hit out
+        nbytes = 32.0 * nodes + 36.0 * tests + 48.0 * n
+        return hits, nodes, tests, nbytes, st.seconds
+
+    hits, nodes, tests, bytes_per_launch, seconds = measure(rays, repeats)
+    achieved = bytes_per_launch / seconds / 1e9
     prim = hits[0].view(torch.int32)
     # HBM traffic per launch comes from PMC passes (rocprofv3 cannot wrap its own caller): profiles/*_traverse_traffic.json holds
     # the counters of the same kernel on the same workload; reported only when the workload matches, else null.
@@ -68,8 +105,23 @@ def traversal_roofline(ctx, n_tris, n_rays, repeats):
            "algorithmic_bytes_per_launch": bytes_per_launch,
            "workload": "%d-triangle soup, %d incoherent rays" % (n_tris, n_rays),
            "bytes_per_ray": round(bytes_per_launch / n_rays, 1), "nodes_per_ray": round(nodes / n_rays, 2), "tris_per_ray": round(tests / n_rays, 2),
-           "launch_ms": round(st.seconds * 1e3, 3), "mrays_per_s": round(n_rays / st.seconds / 1e6, 1),
+           "launch_ms": round(seconds * 1e3, 3), "mrays_per_s": round(n_rays / seconds / 1e6, 1),
            "hit_fraction": round(float((prim >= 0).float().mean().item()), 4)}
+    if bounces > 0:
+        tri_p = torch.from_numpy(scene.tri_p()).to("cuda")
+        batches = [{"bounce": 0, "rays": n_rays, "achieved": round(achieved, 1), "launch_ms": round(seconds * 1e3, 3)}]
+        tot_b, tot_s = bytes_per_launch, seconds
+        for b in range(1, bounces + 1):
+            rays = _next_bounce_rays(rays, hits, tri_p, g)
+            if rays is None:
+                break
+            hits, nodes, tests, nb, sec = measure(rays, max(1, repeats // 2))
+            batches.append({"bounce": b, "rays": int(rays.shape[1]), "achieved": round(nb / sec / 1e9, 1), "launch_ms": round(sec * 1e3, 3),
+                            "nodes_per_ray": round(nodes / rays.shape[1], 1)})
+            tot_b += nb; tot_s += sec
+        out["bounce_batches"] = batches
+        out["all_bounces"] = {"achieved": round(tot_b / tot_s / 1e9, 1), "frac": round(tot_b / tot_s / 1e9 / HBM_PEAK_GBS, 4)}
+        del tri_p
     ds.close(); scene.close()
     return out
 
@@ -104,6 +156,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--soup-tris", type=int, default=10_000_000)
     ap.add_argument("--soup-rays", type=int, default=1 << 24)
+    ap.add_argument("--soup-bounces", type=int, default=4)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -163,7 +216,7 @@ def main():
         }
         if not args.no_roofline:
             try:
-                out["roofline"] = traversal_roofline(ctx, args.soup_tris, args.soup_rays, 5)
+                out["roofline"] = traversal_roofline(ctx, args.soup_tris, args.soup_rays, 5, args.soup_bounces)
             except Exception as e:  # the frame number above is still valid
                 out["roofline"] = {"error": str(e)}
         if world == 1 and not args.no_cpu:
