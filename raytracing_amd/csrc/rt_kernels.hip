@@ -409,7 +409,8 @@ __device__ __forceinline__ F3 to_world(const SurfacePoint &sp, F3 v) {
 
 // One scattering lobe of the hit's BSDF (the shipped materials have exactly one, material.cpp:5-82).
 struct Lobe {
-    int kind;        // 0 none, 1 Lambert, 2 specular reflection, 3 specular transmission, 4 microfacet conductor, 5 metal-roughness
+    int kind;        // 0 none, 1 Lambert, 2 specular reflection, 3 specular transmission, 4 microfacet conductor, 5 metal-roughness,
+                     // 6 microfacet with dielectric Fresnel (etaA = 1.5, etaB = 1: PlasticMaterial, material.cpp:44-47)
     F3 R, eta, k;
     float etaB, metallic;
     TRDist dist;
@@ -419,7 +420,7 @@ __device__ __forceinline__ bool lobe_is_specular(int kind) { return kind == 2 ||
 // BxDF::f in the local frame: reflection.cpp:135-137, 241-249, 268-284.
 __device__ __forceinline__ F3 lobe_f(const Lobe &l, F3 wo, F3 wi) {
     if (l.kind == 1) return f3(l.R.x * RT_INV_PI, l.R.y * RT_INV_PI, l.R.z * RT_INV_PI);
-    if (l.kind == 4 || l.kind == 5) {
+    if (l.kind == 4 || l.kind == 5 || l.kind == 6) {
         float cosO = fabsf(wo.z), cosI = fabsf(wi.z);
         F3 wh = wi + wo;
         if (cosI == 0 || cosO == 0) return f3(0.f, 0.f, 0.f);
@@ -433,6 +434,11 @@ __device__ __forceinline__ F3 lobe_f(const Lobe &l, F3 wo, F3 wi) {
             F3 F = f3(fr_conductor1(ca, l.eta.x, l.k.x), fr_conductor1(ca, l.eta.y, l.k.y), fr_conductor1(ca, l.eta.z, l.k.z));
             float den = 4 * cosI * cosO;
             return cdiv(f3(((l.R.x * Dv) * Gv) * F.x, ((l.R.y * Dv) * Gv) * F.y, ((l.R.z * Dv) * Gv) * F.z), den);
+        }
+        if (l.kind == 6) {
+            float F = fr_dielectric(c, 1.5f, 1.f);
+            float den = 4 * cosI * cosO;
+            return cdiv(f3(((l.R.x * Dv) * Gv) * F, ((l.R.y * Dv) * Gv) * F, ((l.R.z * Dv) * Gv) * F), den);
         }
         float cs = fabsf(c);
         float om = 1 - l.metallic;
@@ -483,7 +489,7 @@ __device__ __forceinline__ F3 lobe_sample(const Lobe &l, F3 wo, float u0, float 
         ft = f3(ft.x * sc, ft.y * sc, ft.z * sc);
         return cdiv(ft, fabsf(wi.z));
     }
-    if (l.kind == 4 || l.kind == 5) {
+    if (l.kind == 4 || l.kind == 5 || l.kind == 6) {
         if (wo.z == 0) return f3(0.f, 0.f, 0.f);
         F3 wh = l.dist.Sample_wh(wo, u0, u1);
         float dwh = dot3(wo, wh);
@@ -494,6 +500,17 @@ __device__ __forceinline__ F3 lobe_sample(const Lobe &l, F3 wo, float u0, float 
         return lobe_f(l, wo, wi);
     }
     return f3(0.f, 0.f, 0.f);
+}
+
+// BxDF::Pdf for a direction another lobe sampled: reflection.cpp:107-109 (Lambert), 262-266 / 296-300 (microfacet lobes).
+__device__ __forceinline__ float lobe_pdf(const Lobe &l, F3 wo, F3 wi) {
+    if (l.kind == 1) return same_hemisphere(wo, wi) ? fabsf(wi.z) * RT_INV_PI : 0.f;
+    if (l.kind == 4 || l.kind == 5 || l.kind == 6) {
+        if (!same_hemisphere(wo, wi)) return 0.f;
+        F3 wh = normalize3(wo + wi);
+        return l.dist.Pdf(wo, wh) / (4 * dot3(wo, wh));
+    }
+    return 0.f;
 }
 
 template <int MAT>
@@ -522,6 +539,9 @@ __device__ __forceinline__ void build_lobe(const DevScene &sc, const DevMaterial
         l.kind = 4; l.R = f3(1.f, 1.f, 1.f);
         l.eta = eval_texture(sc.textures[m.tex[0]], u, v); l.k = eval_texture(sc.textures[m.tex[1]], u, v);
         l.dist.ax = fmaxf(0.001f, ur); l.dist.ay = fmaxf(0.001f, vr);
+    } else if (MAT == RT_MAT_PLASTIC) {          // first lobe only: Lambert(kd) if kd is not black; the glossy lobe is build_plastic_gloss
+        F3 kd = clamp0(eval_texture(sc.textures[m.tex[0]], u, v));
+        if (!black3(kd)) { l.kind = 1; l.R = kd; }
     } else if (MAT == RT_MAT_METALROUGH) {
         F3 c = clamp0(eval_texture(sc.textures[m.tex[0]], u, v));
         if (m.tex[1] < 0) { l.kind = 1; l.R = c; }
@@ -532,6 +552,17 @@ __device__ __forceinline__ void build_lobe(const DevScene &sc, const DevMaterial
             l.dist.ax = fmaxf(0.001f, rough); l.dist.ay = fmaxf(0.001f, rough);
         }
     }
+}
+
+// PlasticMaterial's MicrofacetReflection(ks, TrowbridgeReitz(rough, rough), FresnelDielectric(1.5, 1)), material.cpp:41-48.
+__device__ __forceinline__ void build_plastic_gloss(const DevScene &sc, const DevMaterial &m, float u, float v, Lobe &l) {
+    l.kind = 0; l.R = l.eta = l.k = f3(0.f, 0.f, 0.f); l.etaB = 1.f; l.metallic = 0.f; l.dist.ax = l.dist.ay = 1.f;
+    F3 ks = clamp0(eval_texture(sc.textures[m.tex[1]], u, v));
+    if (black3(ks)) return;
+    float rough = eval_texture(sc.textures[m.tex[2]], u, v).x;
+    if (m.remap) rough = roughness_to_alpha(rough);
+    l.kind = 6; l.R = ks;
+    l.dist.ax = fmaxf(0.001f, rough); l.dist.ay = fmaxf(0.001f, rough);
 }
 
 template <int MAT>
@@ -565,8 +596,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, RenderParams rp
             const DevMaterial &m = sc.materials[sc.slot_material[slot]];
             SurfacePoint sp;
             surface_point(sc, slot, o, d, hb.t[i], hb.b0[i], hb.b1[i], hb.b2[i], material_needs_uv<MAT>(sc, m), sp);
-            Lobe lobe;
+            Lobe lobe, lobe2;       // lobe2: only PlasticMaterial has a second lobe (BSDF::Add order: Lambert, then microfacet)
             build_lobe<MAT>(sc, m, sp.u, sp.v, lobe);
+            lobe2.kind = 0;
+            if (MAT == RT_MAT_PLASTIC) {
+                build_plastic_gloss(sc, m, sp.u, sp.v, lobe2);
+                if (lobe.kind == 0) { lobe = lobe2; lobe2.kind = 0; }
+            }
+            const int nlobes = (MAT == RT_MAT_PLASTIC && lobe2.kind != 0) ? 2 : 1;
             uint32_t pixel = id / (uint32_t)rp.spb, sample = (uint32_t)rp.sample0 + id % (uint32_t)rp.spb;
             uint32_t a0 = pixel, a1 = sample, a2 = (uint32_t)depth, a3 = 0;   // {light pick, uLight.x, uLight.y, roulette}
             philox4x32(a0, a1, a2, a3, rp.k0, rp.k1);
@@ -607,7 +644,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, RenderParams rp
                     F3 f = f3(0.f, 0.f, 0.f);
                     if (wol.z != 0) {
                         bool reflect = dot3(wi, sp.n) * dot3(sp.wo, sp.n) > 0;
-                        if (reflect) f = lobe_f(lobe, wol, wil);
+                        if (reflect) {
+                            f = lobe_f(lobe, wol, wil);
+                            if (nlobes == 2) f = f + lobe_f(lobe2, wol, wil);
+                        }
                     }
                     float ad = fabsf(dot3(wi, sp.n));
                     f = f3(f.x * ad, f.y * ad, f.z * ad);
@@ -619,22 +659,32 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, RenderParams rp
                     }
                 }
             }
-            // ---- BSDF sampling, integrator.cpp:265-279 + BSDF::Sample_f reflection.cpp:173-217 (one lobe)
+            // ---- BSDF sampling, integrator.cpp:265-279 + BSDF::Sample_f reflection.cpp:173-217
             if (lobe.kind != 0) {
                 uint32_t b0 = pixel, b1 = sample, b2 = (uint32_t)depth, b3 = 1;   // {bsdf.x, bsdf.y, -, -}
                 philox4x32(b0, b1, b2, b3, rp.k0, rp.k1);
-                float u0 = fminf(u32_to_unit(b0) * 1 - 0, RT_ONE_MINUS_EPS), u1 = u32_to_unit(b1);
+                // BSDF::Sample_f: component min(floor(u0 * n), n - 1), u0 remapped (reflection.cpp:176-190)
+                float ub = u32_to_unit(b0), u1 = u32_to_unit(b1);
+                int comp = nlobes == 1 ? 0 : min((int)floorf(ub * nlobes), nlobes - 1);
+                float u0 = fminf(ub * nlobes - comp, RT_ONE_MINUS_EPS);
+                Lobe chosen = lobe, other = lobe2;
+                if (nlobes == 2 && comp == 1) { chosen = lobe2; other = lobe; }
                 F3 woW = -d;
                 F3 wol = to_local(sp, woW), wil; float pdf = 0.f;
                 F3 f = f3(0.f, 0.f, 0.f);
                 if (wol.z != 0) {
-                    f = lobe_sample(lobe, wol, u0, u1, wil, pdf);
+                    f = lobe_sample(chosen, wol, u0, u1, wil, pdf);
                     if (pdf == 0) f = f3(0.f, 0.f, 0.f);
                     else {
                         F3 wiW = to_world(sp, wil);
-                        if (!lobe_is_specular(lobe.kind)) {
+                        if (nlobes == 2) { pdf += lobe_pdf(other, wol, wil); pdf /= nlobes; }      // reflection.cpp:199-204
+                        if (!lobe_is_specular(chosen.kind)) {
                             bool reflect = dot3(wiW, sp.n) * dot3(woW, sp.n) > 0;
-                            f = reflect ? lobe_f(lobe, wol, wil) : f3(0.f, 0.f, 0.f);
+                            f = f3(0.f, 0.f, 0.f);
+                            if (reflect) {
+                                f = lobe_f(lobe, wol, wil);
+                                if (nlobes == 2) f = f + lobe_f(lobe2, wol, wil);
+                            }
                         }
                         if (!black3(f) && pdf != 0.f) {
                             float ad = fabsf(dot3(wiW, sp.n));
@@ -648,7 +698,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, RenderParams rp
                             if (alive) {
                                 has_next = true;
                                 no = offset_ray_origin(sp.p, sp.n, wiW); nd = wiW; nT = T * beta;
-                                nstate = (uint32_t)(depth + 1) | (lobe_is_specular(lobe.kind) ? (1u << 16) : 0u);
+                                nstate = (uint32_t)(depth + 1) | (lobe_is_specular(chosen.kind) ? (1u << 16) : 0u);
                             }
                         }
                     }
@@ -1083,8 +1133,7 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     for (int i = 0; i < d->n_materials; ++i) {
         const rt_material &m = d->materials[i];
         if (m.kind < 0 || m.kind >= RT_NUM_CLASSES) { set_error(ctx, "rt_scene_create: unknown material kind"); return -1; }
-        if (m.kind == RT_MAT_PLASTIC) { set_error(ctx, "rt_scene_create: PlasticMaterial (two-lobe BSDF) is not implemented on the device"); return -1; }
-        int need = m.kind == RT_MAT_MATTE || m.kind == RT_MAT_MIRROR ? 1 : m.kind == RT_MAT_GLASS ? 3 : m.kind == RT_MAT_METAL ? 4 : 1;
+        int need = m.kind == RT_MAT_MATTE || m.kind == RT_MAT_MIRROR ? 1 : m.kind == RT_MAT_GLASS || m.kind == RT_MAT_PLASTIC ? 3 : m.kind == RT_MAT_METAL ? 4 : 1;
         for (int k = 0; k < 4; ++k) {
             if (m.tex[k] >= d->n_textures || (k < need && m.tex[k] < 0)) { set_error(ctx, "rt_scene_create: material texture slot out of range"); return -1; }
         }
@@ -1487,6 +1536,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                 if (this_->classes[RT_MAT_MIRROR]) launch_shade<RT_MAT_MIRROR>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->classes[RT_MAT_GLASS]) launch_shade<RT_MAT_GLASS>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->classes[RT_MAT_METAL]) launch_shade<RT_MAT_METAL>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
+                if (this_->classes[RT_MAT_PLASTIC]) launch_shade<RT_MAT_PLASTIC>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->dev.n_lights > 0) {
                     if (frame_old || (lds_scene && b < round_bounces)) {

@@ -72,7 +72,8 @@ void AddCeilingLight(BuiltScene &bs, std::vector<std::shared_ptr<Primitive>> &pr
     }
 }
 
-void BuildCornell(BuiltScene &bs) {
+// plastic: the short cube gets a PlasticMaterial (not in the reference's scene; exercises the two-lobe BSDF of material.cpp:32-49)
+void BuildCornell(BuiltScene &bs, bool plastic = false) {
     std::vector<std::shared_ptr<Primitive>> prims; std::vector<std::shared_ptr<Light>> lights;
     AddCeilingLight(bs, prims, lights, Matte(Spectrum(1.0f, 1.0f, 1.0f)), 20.f);
     std::shared_ptr<Material> mirror = make_shared<MirrorMaterial>(Const(Spectrum(1.f)));
@@ -82,7 +83,9 @@ void BuildCornell(BuiltScene &bs) {
     for (int i = 0; i < 10; ++i) prims.push_back(make_shared<GeometricPrimitive>(room[i], i < 6 ? mwhite : (i < 8 ? mred : mgreen), nullptr));
     Float h = 1.486f;
     auto cube = BoxTriangles(bs, Translate(Vector3f(0.7f, 0.f, 2.8f)) * RotateY(18) * Transform(), 12, h, h, h);
-    for (int i = 0; i < 12; ++i) prims.push_back(make_shared<GeometricPrimitive>(cube[i], mwhite, nullptr));
+    std::shared_ptr<Material> mcube = mwhite;
+    if (plastic) mcube = make_shared<PlasticMaterial>(Const(Spectrum(.25f, .35f, .65f)), Const(Spectrum(.4f, .4f, .4f)), ConstF(0.15f), true);
+    for (int i = 0; i < 12; ++i) prims.push_back(make_shared<GeometricPrimitive>(cube[i], mcube, nullptr));
     // the tall block: its "top" face sits at y = h while the sides reach 2h (RayTracing.cpp:166-167)
     auto block = BoxTriangles(bs, Translate(Vector3f(2.7f, 0.f, 1.0f)) * RotateY(-15) * Transform(), 12, h, h, h * 2);
     for (int i = 0; i < 12; ++i) prims.push_back(make_shared<GeometricPrimitive>(block[i], i < 10 ? mwhite : mirror, nullptr));
@@ -203,6 +206,7 @@ rth_scene *rth_scene_build(const char *name, const char *assets_dir, int64_t par
     rth_scene *h = new rth_scene;
     try {
         if (nm == "cornell") BuildCornell(h->b);
+        else if (nm == "cornell_plastic") BuildCornell(h->b, true);
         else if (nm == "sphere1") BuildSpheres(h->b, false, assets);
         else if (nm == "spheres2") BuildSpheres(h->b, true, assets);
         else if (nm == "helmet") BuildHelmet(h->b, assets);

@@ -37,6 +37,7 @@ TMP = tempfile.mkdtemp(prefix="rt_golden_")
 
 CAMERAS = {   # eye, look, up of the reference's scene functions (RayTracing.cpp:187-190, 406, 315); fov 40, near 0.01 (:424-426)
     "cornell": ((2.5, 2.5, 11.8), (2.5, 2.5, 0.0), (0, 1, 0)),
+    "cornell_plastic": ((2.5, 2.5, 11.8), (2.5, 2.5, 0.0), (0, 1, 0)),
     "sphere1": ((13, 2, 3), (0, 0, 0), (0, 1, 0)),
     "spheres2": ((13, 2, 3), (0, 0, 0), (0, 1, 0)),
     "helmet": ((3.5, 3.2, 1.5), (2.0, 2.3, 2.8), (0, 1, 0)),
@@ -239,6 +240,8 @@ if __name__ == "__main__":
     A, B = ("A", 0), ("B", 1 << 20)
     if not only or "cornell" in only:
         golden_for_scene("cornell", 4096, [(64, 64, 4, 4, [A, B]), (100, 100, 16, 16, [A, B])])
+    if not only or "cornell_plastic" in only:      # the short cube carries a PlasticMaterial (two-lobe BSDF, material.cpp:32-49)
+        golden_for_scene("cornell_plastic", 2048, [(100, 100, 16, 16, [A, B])])
     if not only or "sphere1" in only:
         golden_for_scene("sphere1", 4096, [(64, 64, 4, 4, [A, B])])
     if not only or "spheres2" in only:

@@ -10,7 +10,7 @@ import pytest
 import raytracing_amd as ra
 
 pytestmark = pytest.mark.gpu
-SCENES = ["cornell", "sphere1", "spheres2", "helmet"]
+SCENES = ["cornell", "cornell_plastic", "sphere1", "spheres2", "helmet"]
 
 
 def _rel_close(img, ref, tol):
@@ -122,7 +122,7 @@ def test_trace_edge_cases(device_scene):
     assert prim[0] == -1
 
 
-@pytest.mark.parametrize("name,w,sx", [("cornell", 96, 4), ("sphere1", 96, 4), ("spheres2", 96, 4), ("helmet", 96, 4)])
+@pytest.mark.parametrize("name,w,sx", [("cornell", 96, 4), ("cornell_plastic", 96, 4), ("sphere1", 96, 4), ("spheres2", 96, 4), ("helmet", 96, 4)])
 def test_render_matches_oracle_per_pixel(name, w, sx, device_scene, oracle_scene, host_scene):
     """Same sampler on both sides: identical ray counts (up to a handful of paths whose branch flips on a last-bit libm
     difference) and per-pixel sums equal within 2e-3 relative for all but a few such pixels."""
@@ -138,7 +138,7 @@ def test_render_matches_oracle_per_pixel(name, w, sx, device_scene, oracle_scene
     assert np.all(np.abs(img.mean(axis=(0, 1)) / ref.mean(axis=(0, 1)) - 1) < 2e-3)
 
 
-@pytest.mark.parametrize("name,w,spp", [("cornell", 100, 256), ("spheres2", 96, 64), ("helmet", 96, 64), ("sphere1", 64, 16)])
+@pytest.mark.parametrize("name,w,spp", [("cornell", 100, 256), ("cornell_plastic", 100, 256), ("spheres2", 96, 64), ("helmet", 96, 64), ("sphere1", 64, 16)])
 def test_render_within_reference_noise_floor(name, w, spp, device_scene, host_scene, gold_dir):
     """Against images rendered by the reference's PathIntegrator::Li_re with its own sampler: per-channel mean within
     0.5 % and RMSE (vs the mean of the reference's two seeds) below the reference's own seed-A-vs-seed-B RMSE."""

@@ -11,7 +11,7 @@ import pytest
 import raytracing_amd as ra
 from raytracing_amd import capi
 
-SCENES = ["cornell", "sphere1", "spheres2", "helmet"]
+SCENES = ["cornell", "cornell_plastic", "sphere1", "spheres2", "helmet"]
 
 
 @pytest.mark.parametrize("name", SCENES)
