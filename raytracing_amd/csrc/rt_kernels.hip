@@ -770,7 +770,7 @@ struct RayArrays { const float *ox, *oy, *oz, *dx, *dy, *dz; };
 // (i = its position in the queue arrays).  recs = pair or quad records (LDS or global), slots = leaf slots.
 template <bool ANY, int MODE, class Stack, class Sink>
 __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *recs, const float4 *slots, RayArrays ra, float tmax0, uint32_t lo, uint32_t hi,
-                                            const uint32_t *s_prefix, uint32_t segcap, Stack &st, float *s_ray, int leaf_min, Sink sink) {
+                                            const uint32_t *s_prefix, uint32_t segcap, Stack &st, float *s_ray, Sink sink) {
     const uint32_t lane = lane_id(), wave = threadIdx.x / RT_WAVE;
     const uint32_t per = (((hi - lo) + RT_BLOCK / RT_WAVE - 1) / (RT_BLOCK / RT_WAVE) + RT_WAVE - 1) & ~(uint32_t)(RT_WAVE - 1);
     const uint32_t w_lo = lo + wave * per < hi ? lo + wave * per : hi, w_hi = w_lo + per < hi ? w_lo + per : hi;
@@ -858,7 +858,7 @@ __device__ __forceinline__ void stage_walk_scene(const DevScene &sc, float4 *s_p
 
 template <int MODE>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_pl(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
-                                                         uint32_t segcap, float4 *lbuf, BounceCounts *counts, BounceStats *stats, int *spill, int leaf_min) {
+                                                         uint32_t segcap, float4 *lbuf, BounceCounts *counts, BounceStats *stats, int *spill) {
     __shared__ int s_si[RT_FRAME_RING * RT_BLOCK];
     __shared__ float s_st[RT_FRAME_RING * RT_BLOCK];
     __shared__ float s_rays[(RT_BLOCK / RT_WAVE) * 7 * RT_WAVE];
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_pl(DevScene sc, RenderParam
     st.cap = MODE == RT_WALK_QUADS ? sc.quad_stack_cap : RT_MAX_STACK;
     st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     RayArrays ra = {q.ox, q.oy, q.oz, q.dx, q.dy, q.dz};
-    trace_share<false, MODE>(sc, recs, slots, ra, RT_INF, lo, hi, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE], leaf_min,
+    trace_share<false, MODE>(sc, recs, slots, ra, RT_INF, lo, hi, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE],
                              [&](uint32_t i, const LaneTrav &L) {
                                  hb.slot[i] = L.found ? L.hitSlot : -1; hb.t[i] = L.tmax; hb.b0[i] = L.b0; hb.b1[i] = L.b1; hb.b2[i] = L.b2;
                              });
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_pl(DevScene sc, RenderParam
 
 template <int MODE>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow_pl(DevScene sc, int bounce, ShadowQueue sq, int *occluded, uint32_t segcap, float4 *lbuf, BounceCounts *counts,
-                                                         BounceStats *stats, int *spill, int leaf_min) {
+                                                         BounceStats *stats, int *spill) {
     __shared__ int s_si[RT_FRAME_RING * RT_BLOCK];
     __shared__ float s_st[RT_FRAME_RING * RT_BLOCK];
     __shared__ float s_rays[(RT_BLOCK / RT_WAVE) * 7 * RT_WAVE];
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_pl(DevScene sc, int bounce,
     st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     RayArrays ra = {sq.ox, sq.oy, sq.oz, sq.dx, sq.dy, sq.dz};
     // tMax = 1 - ShadowEpsilon (interaction.h SpawnRayTo)
-    trace_share<true, MODE>(sc, recs, slots, ra, 1.f - 0.0001f, lo, hi, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE], leaf_min,
+    trace_share<true, MODE>(sc, recs, slots, ra, 1.f - 0.0001f, lo, hi, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE],
                             [&](uint32_t i, const LaneTrav &L) { occluded[i] = L.found ? 1 : 0; });
     __threadfence_block();
     __syncthreads();
@@ -1507,7 +1507,6 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     // step), run faster through the one-ray-per-lane-per-round kernels, which have no scheduling overhead (measured on
     // Cornell: 943 / 978 / 985 / 974 Msamples/s for 0 / 1 / 2 / 3 such bounces)
     const int round_bounces = env_int("RT_AMD_FRAME_ROUND_BOUNCES", 2);
-    const int frame_leaf_min = std::max(1, std::min(64, env_int("RT_AMD_FRAME_LEAF_MIN", 16)));
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
         int cur = std::min(spb, o->sample_end - s0);
         rp.spb = cur; rp.sample0 = s0; rp.n_paths = (uint32_t)(npix * (size_t)cur);
@@ -1524,13 +1523,13 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                                        ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
             } else if (walk_mode == RT_WALK_LDS_PAIRS)
                 hipLaunchKernelGGL(k_extend_pl<RT_WALK_LDS_PAIRS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
-                                   (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, frame_leaf_min);
+                                   (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
             else if (walk_mode == RT_WALK_QUADS)
                 hipLaunchKernelGGL(k_extend_pl<RT_WALK_QUADS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
-                                   (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, frame_leaf_min);
+                                   (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
             else
                 hipLaunchKernelGGL(k_extend_pl<RT_WALK_PAIRS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
-                                   (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, frame_leaf_min);
+                                   (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
             if (b < o->max_depth) {
                 if (this_->classes[RT_MAT_MATTE]) launch_shade<RT_MAT_MATTE>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->classes[RT_MAT_MIRROR]) launch_shade<RT_MAT_MIRROR>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
@@ -1548,13 +1547,13 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                                                (int *)this_->d_spill.p);
                     } else if (walk_mode == RT_WALK_LDS_PAIRS)       // the hit buffer's slot array is free once the shading kernels are done
                         hipLaunchKernelGGL(k_shadow_pl<RT_WALK_LDS_PAIRS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, hb.slot, useg, lbuf,
-                                           counts, bstats, (int *)this_->d_spill.p, frame_leaf_min);
+                                           counts, bstats, (int *)this_->d_spill.p);
                     else if (walk_mode == RT_WALK_QUADS)
                         hipLaunchKernelGGL(k_shadow_pl<RT_WALK_QUADS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, hb.slot, useg, lbuf,
-                                           counts, bstats, (int *)this_->d_spill.p, frame_leaf_min);
+                                           counts, bstats, (int *)this_->d_spill.p);
                     else
                         hipLaunchKernelGGL(k_shadow_pl<RT_WALK_PAIRS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, hb.slot, useg, lbuf,
-                                           counts, bstats, (int *)this_->d_spill.p, frame_leaf_min);
+                                           counts, bstats, (int *)this_->d_spill.p);
                 }
             }
             cq ^= 1;
