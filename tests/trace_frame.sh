@@ -5,5 +5,5 @@ R=$PWD
 OUT=$R/gpurun_out/frame_trace
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -- python3 $R/tests/prof_frame.py ${1:-cornell} 800 32 32 > $OUT/run.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -- python3 $R/tests/prof_frame.py ${1:-cornell} 800 ${2:-32} ${2:-32} > $OUT/run.log 2>&1
 echo done
