@@ -292,10 +292,16 @@ __device__ __forceinline__ void stage_scene_lds(const DevScene &sc, float4 *s_no
 
 template <bool LDS_SCENE>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
-                                                      uint32_t segcap, float4 *lbuf, BounceCounts *counts, BounceStats *stats, int *spill) {
+                                                      uint32_t segcap, float4 *lbuf, BounceCounts *counts, BounceStats *stats, int *spill, int fast_walk) {
     __shared__ int s_stack[RT_LDS_STACK * RT_BLOCK];
     __shared__ float4 s_nodes[LDS_SCENE ? 2 * RT_LDS_SCENE_NODES : 1], s_slots[LDS_SCENE ? 3 * RT_LDS_SCENE_SLOTS : 1];
-    if (LDS_SCENE) stage_scene_lds(sc, s_nodes, s_slots);
+    // fast_walk on an LDS scene: the LDS copy holds pair records (k-th float4 of record r at s_nodes[k * 64 + r]) instead of nodes; the int
+    // stack area then carries (node, tMin) entries for 8 levels, which the host guarantees to be enough
+    if (LDS_SCENE && fast_walk) {
+        for (int i = threadIdx.x; i < 4 * sc.n_pairs; i += RT_BLOCK) s_nodes[(i & 3) * (RT_LDS_SCENE_NODES / 2) + (i >> 2)] = sc.pairs[i];
+        for (int i = threadIdx.x; i < 3 * sc.n_slots; i += RT_BLOCK) s_slots[i] = sc.slots[i];
+    } else if (LDS_SCENE) stage_scene_lds(sc, s_nodes, s_slots);
+    PairStackT<8, false> pst; pst.lds_i = &s_stack[threadIdx.x]; pst.lds_t = (float *)&s_stack[8 * RT_BLOCK + threadIdx.x]; pst.reset();
     __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE], s_cls[RT_NUM_CLASSES];
     BounceCounts *bc = counts + bounce;
     if (threadIdx.x < RT_NUM_CLASSES) s_cls[threadIdx.x] = 0;
@@ -307,6 +313,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, RenderParams r
     if (threadIdx.x == 0) { bc->shadow[blockIdx.x] = 0; counts[bounce + 1].queue[blockIdx.x] = 0; }
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     TravStack st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.reset();
+    PairStackT<8, true> gst; gst.lds_i = pst.lds_i; gst.lds_t = pst.lds_t; gst.cap = sc.quad_stack_cap;
+    gst.spill_i = spill + gtid; gst.spill_t = (float *)(spill + (size_t)gst.cap * nthreads) + gtid; gst.spill_stride = nthreads; gst.reset();
     uint32_t seg = lo < hi ? segment_of(s_prefix, lo) : 0;
     const uint32_t seg_base = blockIdx.x * segcap;
     for (uint32_t base = lo; base < hi; base += RT_BLOCK) {
@@ -322,7 +330,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, RenderParams r
             int depth = state & 0xFFFF; bool spec = (state >> 16) & 1;
             HitRec h; uint32_t c0 = 0, c1 = 0;
             bool found;
-            if (LDS_SCENE) { LdsFetch lf; lf.nodes = s_nodes; lf.slots = s_slots; found = traverse<false, false>(sc, lf, o, d, RT_INF, st, h, c0, c1); }
+            if (LDS_SCENE && fast_walk) {
+                LaneTrav L = {};
+                trace_one<false, RT_LDS_SCENE_NODES / 2>(sc, s_nodes, s_slots, o, d, RT_INF, pst, L);
+                found = L.found; h.slot = L.found ? L.hitSlot : -1; h.t = L.tmax; h.b0 = L.b0; h.b1 = L.b1; h.b2 = L.b2;
+            } else if (!LDS_SCENE && fast_walk) {
+                LaneTrav L = {};
+                trace_one<false, 1, true>(sc, sc.quads, sc.slots, o, d, RT_INF, gst, L);
+                found = L.found; h.slot = L.found ? L.hitSlot : -1; h.t = L.tmax; h.b0 = L.b0; h.b1 = L.b1; h.b2 = L.b2;
+            } else if (LDS_SCENE) { LdsFetch lf; lf.nodes = s_nodes; lf.slots = s_slots; found = traverse<false, false>(sc, lf, o, d, RT_INF, st, h, c0, c1); }
             else { GlobalFetch gf; gf.nodes = sc.nodes; gf.slots = sc.slots; found = traverse<false, false>(sc, gf, o, d, RT_INF, st, h, c0, c1); }
             hb.slot[i] = h.slot; hb.t[i] = h.t; hb.b0[i] = h.b0; hb.b1[i] = h.b1; hb.b2[i] = h.b2;
             // integrator.cpp:242-257
@@ -723,10 +739,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, RenderParams rp
 // ------------------------------------------------------------------ shadow --
 template <bool LDS_SCENE>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, ShadowQueue sq, uint32_t segcap, float4 *lbuf, BounceCounts *counts,
-                                                      BounceStats *stats, int *spill) {
+                                                      BounceStats *stats, int *spill, int fast_walk) {
     __shared__ int s_stack[RT_LDS_STACK * RT_BLOCK];
     __shared__ float4 s_nodes[LDS_SCENE ? 2 * RT_LDS_SCENE_NODES : 1], s_slots[LDS_SCENE ? 3 * RT_LDS_SCENE_SLOTS : 1];
-    if (LDS_SCENE) stage_scene_lds(sc, s_nodes, s_slots);
+    // fast_walk on an LDS scene: the LDS copy holds pair records (k-th float4 of record r at s_nodes[k * 64 + r]) instead of nodes; the int
+    // stack area then carries (node, tMin) entries for 8 levels, which the host guarantees to be enough
+    if (LDS_SCENE && fast_walk) {
+        for (int i = threadIdx.x; i < 4 * sc.n_pairs; i += RT_BLOCK) s_nodes[(i & 3) * (RT_LDS_SCENE_NODES / 2) + (i >> 2)] = sc.pairs[i];
+        for (int i = threadIdx.x; i < 3 * sc.n_slots; i += RT_BLOCK) s_slots[i] = sc.slots[i];
+    } else if (LDS_SCENE) stage_scene_lds(sc, s_nodes, s_slots);
+    PairStackT<8, false> pst; pst.lds_i = &s_stack[threadIdx.x]; pst.lds_t = (float *)&s_stack[8 * RT_BLOCK + threadIdx.x]; pst.reset();
     __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE];
     BounceCounts *bc = counts + bounce;
     const uint32_t total = segment_prefix(bc->shadow, s_prefix, s_wave);
@@ -735,6 +757,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, Sh
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_shadow = total;
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     TravStack st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.reset();
+    PairStackT<8, true> gst; gst.lds_i = pst.lds_i; gst.lds_t = pst.lds_t; gst.cap = sc.quad_stack_cap;
+    gst.spill_i = spill + gtid; gst.spill_t = (float *)(spill + (size_t)gst.cap * nthreads) + gtid; gst.spill_stride = nthreads; gst.reset();
     uint32_t seg = lo < hi ? segment_of(s_prefix, lo) : 0;
     for (uint32_t g = lo + threadIdx.x; g < hi; g += RT_BLOCK) {
         while (g >= s_prefix[seg + 1]) seg++;
@@ -742,7 +766,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, Sh
         F3 o = f3(sq.ox[i], sq.oy[i], sq.oz[i]), d = f3(sq.dx[i], sq.dy[i], sq.dz[i]);
         HitRec h; uint32_t c0 = 0, c1 = 0;
         bool occluded;   // tMax = 1 - ShadowEpsilon
-        if (LDS_SCENE) { LdsFetch lf; lf.nodes = s_nodes; lf.slots = s_slots; occluded = traverse<true, false>(sc, lf, o, d, 1.f - 0.0001f, st, h, c0, c1); }
+        if (LDS_SCENE && fast_walk) {
+            LaneTrav L = {};
+            trace_one<true, RT_LDS_SCENE_NODES / 2>(sc, s_nodes, s_slots, o, d, 1.f - 0.0001f, pst, L);
+            occluded = L.found;
+        } else if (!LDS_SCENE && fast_walk) {
+            LaneTrav L = {};
+            trace_one<true, 1, true>(sc, sc.quads, sc.slots, o, d, 1.f - 0.0001f, gst, L);
+            occluded = L.found;
+        } else if (LDS_SCENE) { LdsFetch lf; lf.nodes = s_nodes; lf.slots = s_slots; occluded = traverse<true, false>(sc, lf, o, d, 1.f - 0.0001f, st, h, c0, c1); }
         else { GlobalFetch gf; gf.nodes = sc.nodes; gf.slots = sc.slots; occluded = traverse<true, false>(sc, gf, o, d, 1.f - 0.0001f, st, h, c0, c1); }
         if (!occluded) {
             uint32_t id = sq.id[i];
@@ -754,15 +786,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, Sh
 }
 
 // ------------------------------------------------ persistent-lane frame tracing --
-// k_extend / k_shadow above give every lane one ray per round and the wave waits for its slowest lane: on Cornell only a
-// third of the lanes are busy on average.  The kernels below walk the same queues with persistent lanes (rt_traverse2.h):
-// a lane that finishes its ray takes the next one of its wave's range at once.  Rays are staged through LDS a batch of 64
-// at a time (coalesced loads issued one batch ahead), so a refill never waits on global memory; results go out with plain
-// stores; everything that needs a global read-modify-write or a wave-wide append (emission, class binning, adding the
-// unoccluded light) runs afterwards as a second, coalesced sweep over the block's share.
+// k_extend / k_shadow above give every lane one ray per round and the wave waits for its slowest lane: fine while rays
+// take similar numbers of steps, wasteful on deep trees with incoherent rays.  The kernels below walk the same queues with
+// persistent lanes over records in HBM (rt_traverse2.h): a lane that finishes its ray takes the next one of its wave's range
+// at once.  Rays are staged through LDS a batch of 64 at a time (coalesced loads issued one batch ahead), so a refill never
+// waits on global memory; results go out with plain stores; everything that needs a global read-modify-write or a
+// wave-wide append (emission, class binning, adding the unoccluded light) runs afterwards as a second, coalesced sweep
+// over the block's share.
 #define RT_FRAME_RING 8          // LDS ring entries per lane (node, tMin)
-#define RT_LDS_SCENE_PAIRS (RT_LDS_SCENE_NODES / 2)
-enum { RT_WALK_LDS_PAIRS = 0, RT_WALK_QUADS = 1, RT_WALK_PAIRS = 2 };
+enum { RT_WALK_QUADS = 1, RT_WALK_PAIRS = 2 };
 
 struct RayArrays { const float *ox, *oy, *oz, *dx, *dy, *dz; };
 
@@ -808,9 +840,8 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
                 if (__ballot(walk && !L.plain) == 0) { if (walk) lane_walk_quad<true>(recs, L, st, info, have); }     // the whole wave takes one version
                 else if (walk) lane_walk_quad<false>(recs, L, st, info, have);
             } else {
-                constexpr int KS = MODE == RT_WALK_LDS_PAIRS ? RT_LDS_SCENE_PAIRS : 1;
-                if (__ballot(walk && !L.plain) == 0) { if (walk) lane_walk<false, true, KS>(recs, L, st, dummy, info, have); }
-                else if (walk) lane_walk<false, false, KS>(recs, L, st, dummy, info, have);
+                if (__ballot(walk && !L.plain) == 0) { if (walk) lane_walk<false, true>(recs, L, st, dummy, info, have); }
+                else if (walk) lane_walk<false, false>(recs, L, st, dummy, info, have);
             }
             moved = walk;
         } else if (nL >= nI) {
@@ -846,36 +877,24 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
     if (busy && L.mode == RT_LANE_DONE) sink(cur_i, L);
 }
 
-// Scene records for trace_share: an LDS copy of pair records and slots (small scenes), else quad or pair records in HBM.
-template <int MODE>
-__device__ __forceinline__ void stage_walk_scene(const DevScene &sc, float4 *s_pairs, float4 *s_slots, const float4 *&recs, const float4 *&slots) {
-    if (MODE == RT_WALK_LDS_PAIRS) {
-        for (int i = threadIdx.x; i < 4 * sc.n_pairs; i += RT_BLOCK) s_pairs[(i & 3) * RT_LDS_SCENE_PAIRS + (i >> 2)] = sc.pairs[i];
-        for (int i = threadIdx.x; i < 3 * sc.n_slots; i += RT_BLOCK) s_slots[i] = sc.slots[i];
-        recs = s_pairs; slots = s_slots;
-    } else { recs = MODE == RT_WALK_QUADS ? sc.quads : sc.pairs; slots = sc.slots; }
-}
-
 template <int MODE>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend_pl(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
                                                          uint32_t segcap, float4 *lbuf, BounceCounts *counts, BounceStats *stats, int *spill) {
     __shared__ int s_si[RT_FRAME_RING * RT_BLOCK];
     __shared__ float s_st[RT_FRAME_RING * RT_BLOCK];
     __shared__ float s_rays[(RT_BLOCK / RT_WAVE) * 7 * RT_WAVE];
-    __shared__ float4 s_pairs[MODE == RT_WALK_LDS_PAIRS ? 4 * RT_LDS_SCENE_PAIRS : 1], s_slots[MODE == RT_WALK_LDS_PAIRS ? 3 * RT_LDS_SCENE_SLOTS : 1];
     __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE], s_cls[RT_NUM_CLASSES];
-    const float4 *recs, *slots;
-    stage_walk_scene<MODE>(sc, s_pairs, s_slots, recs, slots);
+    const float4 *recs = MODE == RT_WALK_QUADS ? sc.quads : sc.pairs, *slots = sc.slots;
     BounceCounts *bc = counts + bounce;
     if (threadIdx.x < RT_NUM_CLASSES) s_cls[threadIdx.x] = 0;
-    const uint32_t total = segment_prefix(bc->queue, s_prefix, s_wave);      // its barriers also cover the staging above
+    const uint32_t total = segment_prefix(bc->queue, s_prefix, s_wave);
     uint32_t lo, hi;
     block_share(total, lo, hi);
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_queue = total;
     // the shading kernels of this bounce append to segment blockIdx.x of the shadow queue and of the next queue
     if (threadIdx.x == 0) { bc->shadow[blockIdx.x] = 0; counts[bounce + 1].queue[blockIdx.x] = 0; }
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    PairStackT<RT_FRAME_RING, MODE != RT_WALK_LDS_PAIRS> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
+    PairStackT<RT_FRAME_RING> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
     st.cap = MODE == RT_WALK_QUADS ? sc.quad_stack_cap : RT_MAX_STACK;
     st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     RayArrays ra = {q.ox, q.oy, q.oz, q.dx, q.dy, q.dz};
@@ -944,17 +963,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_pl(DevScene sc, int bounce,
     __shared__ int s_si[RT_FRAME_RING * RT_BLOCK];
     __shared__ float s_st[RT_FRAME_RING * RT_BLOCK];
     __shared__ float s_rays[(RT_BLOCK / RT_WAVE) * 7 * RT_WAVE];
-    __shared__ float4 s_pairs[MODE == RT_WALK_LDS_PAIRS ? 4 * RT_LDS_SCENE_PAIRS : 1], s_slots[MODE == RT_WALK_LDS_PAIRS ? 3 * RT_LDS_SCENE_SLOTS : 1];
     __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE];
-    const float4 *recs, *slots;
-    stage_walk_scene<MODE>(sc, s_pairs, s_slots, recs, slots);
+    const float4 *recs = MODE == RT_WALK_QUADS ? sc.quads : sc.pairs, *slots = sc.slots;
     BounceCounts *bc = counts + bounce;
     const uint32_t total = segment_prefix(bc->shadow, s_prefix, s_wave);
     uint32_t lo, hi;
     block_share(total, lo, hi);
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_shadow = total;
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    PairStackT<RT_FRAME_RING, MODE != RT_WALK_LDS_PAIRS> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
+    PairStackT<RT_FRAME_RING> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
     st.cap = MODE == RT_WALK_QUADS ? sc.quad_stack_cap : RT_MAX_STACK;
     st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     RayArrays ra = {sq.ox, sq.oy, sq.oz, sq.dx, sq.dy, sq.dz};
@@ -1502,11 +1519,14 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     // scenes small enough are traversed out of an LDS copy (no spheres: their records stay in global memory)
     const bool lds_scene = this_->dev.n_nodes <= RT_LDS_SCENE_NODES && this_->dev.n_slots <= RT_LDS_SCENE_SLOTS && this_->interior_depth <= RT_FRAME_RING;
     const bool frame_old = env_int("RT_AMD_FRAME_NODE_WALK", 0) != 0;       // knob: the one-ray-per-lane-per-round kernels
-    const int walk_mode = lds_scene ? RT_WALK_LDS_PAIRS : (this_->dev.quads ? RT_WALK_QUADS : RT_WALK_PAIRS);
-    // On LDS-resident scenes the first bounces, whose rays are the most coherent (lanes of a wave finish at about the same
-    // step), run faster through the one-ray-per-lane-per-round kernels, which have no scheduling overhead (measured on
-    // Cornell: 943 / 978 / 985 / 974 Msamples/s for 0 / 1 / 2 / 3 such bounces)
-    const int round_bounces = env_int("RT_AMD_FRAME_ROUND_BOUNCES", 2);
+    const int walk_mode = this_->dev.quads ? RT_WALK_QUADS : RT_WALK_PAIRS;
+    // Which walk for which bounce.  Round-based kernels (one ray per lane per round, no scheduling overhead) win while the
+    // rays of a wave take about the same number of steps: always on small trees, and for camera rays on large ones;
+    // persistent lanes win on deep trees once the rays are incoherent.  Measured, Msamples/s: Cornell 1174 round-based
+    // vs 1002 persistent; spheres 3445 vs 3169; helmet 273 round-based, 328 persistent, 346 with only bounce 0 round-based.
+    const int round_bounces = env_int("RT_AMD_FRAME_ROUND_BOUNCES", this_->dev.n_nodes <= 4096 ? 1 << 20 : 1);
+    const int round_pairs = (this_->interior_depth <= 8 && env_int("RT_AMD_ROUND_PAIRS", 1)) ? 1 : 0;
+    const int round_quads = (this_->dev.quads && env_int("RT_AMD_ROUND_PAIRS", 1)) ? 1 : 0;
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
         int cur = std::min(spb, o->sample_end - s0);
         rp.spb = cur; rp.sample0 = s0; rp.n_paths = (uint32_t)(npix * (size_t)cur);
@@ -1514,17 +1534,14 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
         hipLaunchKernelGGL(k_raygen, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, rp, q[0], useg, lbuf, counts);
         int cq = 0;
         for (int b = 0; b <= o->max_depth; ++b) {
-            if (frame_old || (lds_scene && b < round_bounces)) {
+            if (frame_old || b < round_bounces) {
                 if (lds_scene)
                     hipLaunchKernelGGL(k_extend<true>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
-                                       ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
+                                       ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, round_pairs);
                 else
                     hipLaunchKernelGGL(k_extend<false>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
-                                       ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
-            } else if (walk_mode == RT_WALK_LDS_PAIRS)
-                hipLaunchKernelGGL(k_extend_pl<RT_WALK_LDS_PAIRS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
-                                   (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
-            else if (walk_mode == RT_WALK_QUADS)
+                                       ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, round_quads);
+            } else if (walk_mode == RT_WALK_QUADS)
                 hipLaunchKernelGGL(k_extend_pl<RT_WALK_QUADS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
                                    (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
             else
@@ -1538,17 +1555,14 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                 if (this_->classes[RT_MAT_PLASTIC]) launch_shade<RT_MAT_PLASTIC>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
                 if (this_->dev.n_lights > 0) {
-                    if (frame_old || (lds_scene && b < round_bounces)) {
+                    if (frame_old || b < round_bounces) {
                         if (lds_scene)
                             hipLaunchKernelGGL(k_shadow<true>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
-                                               (int *)this_->d_spill.p);
+                                               (int *)this_->d_spill.p, round_pairs);
                         else
                             hipLaunchKernelGGL(k_shadow<false>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
-                                               (int *)this_->d_spill.p);
-                    } else if (walk_mode == RT_WALK_LDS_PAIRS)       // the hit buffer's slot array is free once the shading kernels are done
-                        hipLaunchKernelGGL(k_shadow_pl<RT_WALK_LDS_PAIRS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, hb.slot, useg, lbuf,
-                                           counts, bstats, (int *)this_->d_spill.p);
-                    else if (walk_mode == RT_WALK_QUADS)
+                                               (int *)this_->d_spill.p, round_quads);
+                    } else if (walk_mode == RT_WALK_QUADS)       // the hit buffer's slot array is free once the shading kernels are done
                         hipLaunchKernelGGL(k_shadow_pl<RT_WALK_QUADS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, hb.slot, useg, lbuf,
                                            counts, bstats, (int *)this_->d_spill.p);
                     else

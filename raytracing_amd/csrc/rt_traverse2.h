@@ -308,3 +308,30 @@ __device__ __forceinline__ LeafOut lane_leaf(const DevScene &sc, const float4 *s
     }
     return r;
 }
+
+// One ray per lane, run to completion (the round-based frame kernels): interior steps until every lane of the wave that is
+// still walking has reached a leaf or finished, then the leaf tests together — the same pair records, slab tests and
+// per-ray constants as the persistent walk, without its scheduling.
+// QUADS: `pairs` holds quad records (KSTRIDE ignored).
+template <bool ANY, int KSTRIDE, bool QUADS = false, class Stack>
+__device__ __forceinline__ void trace_one(const DevScene &sc, const float4 *pairs, const float4 *slots, F3 o, F3 d, float tmax, Stack &st, LaneTrav &L) {
+    uint32_t dummy = 0;
+    bool have = lane_begin<false>(sc, L, st, o, d, tmax, dummy);
+    lane_enter(sc, L, sc.root_info, have);
+    while (L.mode != RT_LANE_DONE) {
+        while (L.mode == RT_LANE_WALK) {
+            uint32_t info; bool hv;
+            if (QUADS) {
+                if (L.plain) lane_walk_quad<true>(pairs, L, st, info, hv);
+                else lane_walk_quad<false>(pairs, L, st, info, hv);
+            } else if (L.plain) lane_walk<false, true, KSTRIDE>(pairs, L, st, dummy, info, hv);
+            else lane_walk<false, false, KSTRIDE>(pairs, L, st, dummy, info, hv);
+            lane_enter(sc, L, info, hv);
+        }
+        if (L.mode == RT_LANE_LEAF) {
+            LeafOut r = lane_leaf<ANY, false>(sc, slots, L, st, dummy);
+            L.found = r.found; L.tmax = r.tmax; L.hitSlot = r.hitSlot; L.b0 = r.b0; L.b1 = r.b1; L.b2 = r.b2;
+            lane_enter(sc, L, r.info, r.have);
+        }
+    }
+}
