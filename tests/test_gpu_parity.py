@@ -180,6 +180,45 @@ def test_render_properties_at_full_size(device_scene, host_scene):
     assert np.all(np.abs(other.mean(axis=(0, 1)) / full.mean(axis=(0, 1)) - 1) < 0.005)
 
 
+@pytest.mark.parametrize("name,w", [("cornell", 200), ("helmet", 160), ("spheres2", 160)])
+def test_frame_walks_give_identical_images(name, w, device_scene, host_scene, monkeypatch):
+    """The frame kernels have three walks (round-based over pair/quad records, persistent lanes, round-based over plain
+    nodes).  Traversal is bit-exact in all of them and every sample is a pure function of (pixel, sample), so the images
+    must be identical to the last bit."""
+    ds = device_scene(name)
+    cam = host_scene(name).camera(w, w)
+    base, st = ds.render(cam, ra.make_opts(4, 2))
+    for env in ({"RT_AMD_FRAME_ROUND_BOUNCES": "0"}, {"RT_AMD_FRAME_ROUND_BOUNCES": "1000"}, {"RT_AMD_FRAME_NODE_WALK": "1", "RT_AMD_ROUND_PAIRS": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        img, st2 = ds.render(cam, ra.make_opts(4, 2))
+        for k in env:
+            monkeypatch.delenv(k)
+        assert st2.rays_closest == st.rays_closest and st2.rays_shadow == st.rays_shadow, env
+        assert np.array_equal(img, base), env
+
+
+def test_scene_create_rejects_inconsistent_descriptions(host_scene, gpu_ctx):
+    """Indices and tree links are validated on the host before any kernel can follow them."""
+    import ctypes as C
+    hs = host_scene("cornell")
+    for field, bad in (("prim_material", 99), ("prim_geom", 10 ** 6), ("prim_light", 77)):
+        d = type(hs.desc).from_buffer_copy(hs.desc)             # shallow copy of the struct; swap one array
+        n = d.n_prims
+        arr = (C.c_int32 * n)(*[getattr(hs.desc, field)[i] for i in range(n)])
+        arr[3] = bad
+        setattr(d, field, C.cast(arr, C.POINTER(C.c_int32)))
+        with pytest.raises(RuntimeError):
+            ra.DeviceScene(gpu_ctx, C.pointer(d))
+    d = type(hs.desc).from_buffer_copy(hs.desc)
+    nodes = (ra.capi.BvhNode * d.n_nodes)()
+    C.memmove(nodes, hs.desc.bvh_nodes, 32 * d.n_nodes)
+    nodes[0].offset = d.n_nodes + 5                              # second child beyond the array
+    d.bvh_nodes = C.cast(nodes, C.POINTER(ra.capi.BvhNode))
+    with pytest.raises(RuntimeError):
+        ra.DeviceScene(gpu_ctx, C.pointer(d))
+
+
 def test_max_depth_zero_and_one(device_scene, oracle_scene, host_scene):
     cam = host_scene("cornell").camera(64, 64)
     for md in (0, 1, 4):
