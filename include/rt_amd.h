@@ -181,6 +181,13 @@ const char *rt_last_error(rt_ctx *ctx);   /* ctx may be NULL for rt_init failure
 int rt_bvh_build(int32_t n_prims, const float *prim_bounds,
                  rt_bvh_node *nodes_out, int32_t *n_nodes_out, int32_t *order_out);
 
+/* The same builder with the other two constructor arguments of BVHAccel (include/core/bvh.h:17-20):
+ * maxPrimsInNode (clamped to 255, bvh.cpp:65; only the SAH rule reads it, bvh.cpp:195) and the split method, numbered
+ * as the reference's enum.  HLBVH has no builder of its own in the reference and takes the SAH case (bvh.cpp:143-144). */
+enum { RT_SPLIT_SAH = 0, RT_SPLIT_HLBVH = 1, RT_SPLIT_MIDDLE = 2, RT_SPLIT_EQUAL_COUNTS = 3 };
+int rt_bvh_build_ex(int32_t n_prims, const float *prim_bounds, int32_t max_prims_in_node, int32_t split_method,
+                    rt_bvh_node *nodes_out, int32_t *n_nodes_out, int32_t *order_out);
+
 /* World bounds of every primitive of a desc, n_prims*6 floats
  * (Triangle::WorldBound triangle.cpp:45-50, Shape::WorldBound shape.cpp:16 for spheres). */
 int rt_prim_bounds(const rt_scene_desc *desc, float *bounds_out);

@@ -144,7 +144,9 @@ static void LoadScene(const std::string &path, RefScene &rs) {
         rs.primIndex[gp.get()] = i;
         rs.prims.push_back(gp);
     }
-    rs.bvh = std::make_shared<BVHAccel>(rs.prims);
+    // REF_BVH_MAXPRIMS / REF_BVH_SPLIT select the other constructor arguments (bvh.h:17-20); unset = the reference's defaults
+    const char *mp = getenv("REF_BVH_MAXPRIMS"), *sm = getenv("REF_BVH_SPLIT");
+    rs.bvh = std::make_shared<BVHAccel>(rs.prims, mp ? atoi(mp) : 1, sm ? (BVHAccel::SplitMethod)atoi(sm) : BVHAccel::SplitMethod::Middle);
     rs.scene = std::make_shared<Scene>(rs.bvh, rs.lights);
 }
 

@@ -163,6 +163,16 @@ inline int MaximumExtent(Bounds b) {
     if (d.x > d.y && d.x > d.z) return 0; else if (d.y > d.z) return 1; else return 2;
 }
 
+// Bounds3::SurfaceArea geometry.h:772-775, Bounds3::Offset geometry.h:794-800
+inline Float SurfaceAreaB(Bounds b) { V3 d = b.pMax - b.pMin; return 2 * (d.x * d.y + d.x * d.z + d.y * d.z); }
+inline V3 OffsetB(Bounds b, V3 p) {
+    V3 o = p - b.pMin;
+    if (b.pMax.x > b.pMin.x) o.x /= b.pMax.x - b.pMin.x;
+    if (b.pMax.y > b.pMin.y) o.y /= b.pMax.y - b.pMin.y;
+    if (b.pMax.z > b.pMin.z) o.z /= b.pMax.z - b.pMin.z;
+    return o;
+}
+
 // ------------------------------------------------------------- BVH build --
 // bvh.cpp:9-18
 struct PrimInfo { size_t primitiveNumber; Bounds bounds; V3 centroid; };
@@ -170,9 +180,10 @@ struct BuildNode { Bounds bounds; BuildNode *children[2]; int splitAxis, firstPr
 
 struct Builder {
     std::vector<PrimInfo> info; std::vector<int32_t> ordered; std::vector<BuildNode *> pool; int totalNodes = 0;
+    int maxPrimsInNode = 1, splitMethod = 2;   // bvh.h:17-20: enum SplitMethod { SAH, HLBVH, Middle, EqualCounts }
     BuildNode *alloc() { BuildNode *n = new BuildNode; pool.push_back(n); return n; }
     ~Builder() { for (BuildNode *n : pool) delete n; }
-    // bvh.cpp:86-227, SplitMethod::Middle with the EqualCounts fall-through.
+    // bvh.cpp:86-227
     BuildNode *recursiveBuild(int start, int end) {
         BuildNode *node = alloc();
         totalNodes++;
@@ -192,14 +203,59 @@ struct Builder {
         int dim = MaximumExtent(cb);
         int mid = (start + end) / 2;
         if (cb.pMax[dim] == cb.pMin[dim]) return leaf();
-        Float pmid = (cb.pMin[dim] + cb.pMax[dim]) / 2;
-        PrimInfo *midPtr = std::partition(&info[start], &info[end - 1] + 1,
-                                          [dim, pmid](const PrimInfo &pi) { return pi.centroid[dim] < pmid; });
-        mid = (int)(midPtr - &info[0]);
-        if (!(mid != start && mid != end)) {
+        switch (splitMethod) {
+        case 2: {   // SplitMethod::Middle, bvh.cpp:122-132
+            Float pmid = (cb.pMin[dim] + cb.pMax[dim]) / 2;
+            PrimInfo *midPtr = std::partition(&info[start], &info[end - 1] + 1,
+                                              [dim, pmid](const PrimInfo &pi) { return pi.centroid[dim] < pmid; });
+            mid = (int)(midPtr - &info[0]);
+            if (mid != start && mid != end) break;
+        }   // falls through, as the reference does
+        case 3: {   // SplitMethod::EqualCounts, bvh.cpp:133-142
             mid = (start + end) / 2;
             std::nth_element(&info[start], &info[mid], &info[end - 1] + 1,
                              [dim](const PrimInfo &a, const PrimInfo &b) { return a.centroid[dim] < b.centroid[dim]; });
+            break;
+        }
+        default: {  // SplitMethod::SAH and HLBVH, bvh.cpp:143-217
+            if (nPrimitives <= 2) {
+                mid = (start + end) / 2;
+                std::nth_element(&info[start], &info[mid], &info[end - 1] + 1,
+                                 [dim](const PrimInfo &a, const PrimInfo &b) { return a.centroid[dim] < b.centroid[dim]; });
+            } else {
+                const int nBuckets = 12;
+                struct Bucket { int count = 0; Bounds bounds = EmptyBounds(); } buckets[nBuckets];
+                auto bucketOf = [&cb, dim](const PrimInfo &pi) {
+                    int b = nBuckets * OffsetB(cb, pi.centroid)[dim];
+                    if (b == nBuckets) b = nBuckets - 1;
+                    return b;
+                };
+                for (int i = start; i < end; ++i) {
+                    int b = bucketOf(info[i]);
+                    buckets[b].count++;
+                    buckets[b].bounds = UnionBB(buckets[b].bounds, info[i].bounds);
+                }
+                Float cost[nBuckets - 1];
+                for (int i = 0; i < nBuckets - 1; ++i) {
+                    Bounds b0 = EmptyBounds(), b1 = EmptyBounds();
+                    int count0 = 0, count1 = 0;
+                    for (int j = 0; j <= i; ++j) { b0 = UnionBB(b0, buckets[j].bounds); count0 += buckets[j].count; }
+                    for (int j = i + 1; j < nBuckets; ++j) { b1 = UnionBB(b1, buckets[j].bounds); count1 += buckets[j].count; }
+                    cost[i] = 1 + (count0 * SurfaceAreaB(b0) + count1 * SurfaceAreaB(b1)) / SurfaceAreaB(bounds);
+                }
+                Float minCost = cost[0];
+                int minCostSplitBucket = 0;
+                for (int i = 1; i < nBuckets - 1; ++i)
+                    if (cost[i] < minCost) { minCost = cost[i]; minCostSplitBucket = i; }
+                Float leafCost = nPrimitives;
+                if (nPrimitives > maxPrimsInNode || minCost < leafCost) {
+                    PrimInfo *pmid = std::partition(&info[start], &info[end - 1] + 1,
+                                                    [&](const PrimInfo &pi) { return bucketOf(pi) <= minCostSplitBucket; });
+                    mid = (int)(pmid - &info[0]);
+                } else return leaf();
+            }
+            break;
+        }
         }
         BuildNode *c0 = recursiveBuild(start, mid);
         BuildNode *c1 = recursiveBuild(mid, end);
@@ -226,9 +282,10 @@ struct Builder {
     }
 };
 
-int bvh_build(int n, const float *pb, rt_bvh_node *nodes_out, int32_t *n_nodes_out, int32_t *order_out) {
+int bvh_build(int n, const float *pb, rt_bvh_node *nodes_out, int32_t *n_nodes_out, int32_t *order_out, int maxPrims = 1, int method = 2) {
     if (n <= 0) { *n_nodes_out = 0; return 0; }
     Builder b; b.info.resize(n);
+    b.maxPrimsInNode = std::min(255, maxPrims); b.splitMethod = method;   // bvh.cpp:65
     for (int i = 0; i < n; ++i) {
         Bounds bb = {mk(pb[6 * i], pb[6 * i + 1], pb[6 * i + 2]), mk(pb[6 * i + 3], pb[6 * i + 4], pb[6 * i + 5])};
         b.info[i].primitiveNumber = i; b.info[i].bounds = bb;
@@ -1073,6 +1130,9 @@ struct orc_scene { Scene s; };
 
 int orc_bvh_build(int32_t n, const float *prim_bounds, rt_bvh_node *nodes_out, int32_t *n_nodes_out, int32_t *order_out) {
     return bvh_build(n, prim_bounds, nodes_out, n_nodes_out, order_out);
+}
+int orc_bvh_build_ex(int32_t n, const float *prim_bounds, int32_t max_prims, int32_t method, rt_bvh_node *nodes_out, int32_t *n_nodes_out, int32_t *order_out) {
+    return bvh_build(n, prim_bounds, nodes_out, n_nodes_out, order_out, max_prims, method);
 }
 int orc_prim_bounds(const rt_scene_desc *d, float *out) { prim_bounds(d, out); return 0; }
 

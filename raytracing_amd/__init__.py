@@ -102,13 +102,15 @@ class HostScene:
             pass
 
 
-def bvh_build(bounds):
+def bvh_build(bounds, max_prims_in_node=1, split_method=2):
+    """split_method: RT_SPLIT_* of rt_amd.h = the reference's enum SplitMethod { SAH, HLBVH, Middle, EqualCounts }."""
     bounds = np.ascontiguousarray(bounds, np.float32).reshape(-1, 6)
     n = bounds.shape[0]
     nodes = np.zeros(max(2 * n, 1), BVH_NODE_DTYPE)
     order = np.zeros(max(n, 1), np.int32)
     nn = C.c_int32(0)
-    rc = rt().rt_bvh_build(n, capi.fptr(bounds), nodes.ctypes.data_as(C.POINTER(capi.BvhNode)), C.byref(nn), capi.iptr(order))
+    rc = rt().rt_bvh_build_ex(n, capi.fptr(bounds), max_prims_in_node, split_method, nodes.ctypes.data_as(C.POINTER(capi.BvhNode)), C.byref(nn),
+                              capi.iptr(order))
     if rc != 0:
         raise RuntimeError("rt_bvh_build failed")
     return nodes[:nn.value].copy(), order[:n].copy()

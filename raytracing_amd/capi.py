@@ -78,7 +78,7 @@ RT_RENDER_ACCUMULATE = 1
 
 # Every symbol include/rt_amd.h declares.
 RT_AMD_SYMBOLS = [
-    "rt_version", "rt_init", "rt_shutdown", "rt_last_error", "rt_bvh_build", "rt_prim_bounds", "rt_scene_create",
+    "rt_version", "rt_init", "rt_shutdown", "rt_last_error", "rt_bvh_build", "rt_bvh_build_ex", "rt_prim_bounds", "rt_scene_create",
     "rt_scene_destroy", "rt_scene_get_bvh", "rt_trace_closest", "rt_trace_any", "rt_trace_closest_device",
     "rt_render", "rt_render_device", "rt_tonemap_u8",
 ]
@@ -100,6 +100,7 @@ def load_rt_amd():
     lib.rt_shutdown.argtypes = [vp]; lib.rt_shutdown.restype = None
     lib.rt_last_error.argtypes = [vp]; lib.rt_last_error.restype = C.c_char_p
     lib.rt_bvh_build.argtypes = [C.c_int32, f32p, C.POINTER(BvhNode), i32p, i32p]
+    lib.rt_bvh_build_ex.argtypes = [C.c_int32, f32p, C.c_int32, C.c_int32, C.POINTER(BvhNode), i32p, i32p]
     lib.rt_prim_bounds.argtypes = [C.POINTER(SceneDesc), f32p]
     lib.rt_scene_create.argtypes = [vp, C.POINTER(SceneDesc), C.POINTER(vp)]
     lib.rt_scene_destroy.argtypes = [vp]; lib.rt_scene_destroy.restype = None

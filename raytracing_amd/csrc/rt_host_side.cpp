@@ -28,49 +28,92 @@ struct Box {
 // (bvh.cpp:105-141); node boxes are unions of the children's boxes, which equals the
 // reference's loop over the range because min/max never round.  Leaf slots are handed out
 // in depth-first order.
+// Split rules of BVHAccel::recursiveBuild (bvh.cpp:86-227).  The enum values are the reference's (bvh.h:17); HLBVH has no
+// builder of its own there and falls into the SAH case of the switch (bvh.cpp:143-144).
 struct TreeEmitter {
     std::vector<Item> items;
     const float *bounds;   // n*6
     rt_bvh_node *nodes;
     int32_t *order;
     int32_t nNodes = 0, nSlots = 0;
+    int maxPrims = 1, method = RT_SPLIT_MIDDLE;
+
+    static float area(const Box &b) {    // Bounds3::SurfaceArea, geometry.h:772-775
+        float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+        return 2 * (dx * dy + dx * dz + dy * dz);
+    }
+    // bucket of a centroid along dim: 12 * Bounds3::Offset (geometry.h:794-800), truncated, last bucket closed (bvh.cpp:159-162)
+    static int bucket(const Box &cb, const float *c, int dim) {
+        float o = c[dim] - cb.lo[dim];
+        if (cb.hi[dim] > cb.lo[dim]) o /= cb.hi[dim] - cb.lo[dim];
+        int b = (int)(12 * o);
+        return b == 12 ? 11 : b;
+    }
 
     Box emit(int start, int end) {
         int32_t me = nNodes++;
-        rt_bvh_node &node = nodes[me];
-        std::memset(&node, 0, sizeof(node));
+        std::memset(&nodes[me], 0, sizeof(rt_bvh_node));
         int count = end - start;
         Box cb; cb.reset();
         for (int i = start; i < end; ++i) cb.grow(items[i].c);
         float dx = cb.hi[0] - cb.lo[0], dy = cb.hi[1] - cb.lo[1], dz = cb.hi[2] - cb.lo[2];
         int dim = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);   // Bounds3::MaximumExtent, geometry.h:780-788
+        Box all; all.reset();                                      // bounds of the range (bvh.cpp:92-94)
+        for (int i = start; i < end; ++i) { const float *b = bounds + 6 * (size_t)items[i].id; all.grow(b); all.grow(b + 3); }
+        bool leaf = count == 1 || cb.hi[dim] == cb.lo[dim];
+        int mid = (start + end) / 2;
+        Item *first = items.data() + start, *last = items.data() + end;
+        auto equalCounts = [&]() {
+            mid = (start + end) / 2;
+            std::nth_element(first, items.data() + mid, last, [dim](const Item &a, const Item &b) { return a.c[dim] < b.c[dim]; });
+        };
+        if (!leaf) {
+            if (method == RT_SPLIT_MIDDLE) {
+                float pmid = (cb.lo[dim] + cb.hi[dim]) / 2;
+                Item *m = std::partition(first, last, [dim, pmid](const Item &it) { return it.c[dim] < pmid; });
+                mid = (int)(m - items.data());
+                if (mid == start || mid == end) equalCounts();     // the reference's case fall-through (bvh.cpp:131-133)
+            } else if (method == RT_SPLIT_EQUAL_COUNTS) equalCounts();
+            else if (count <= 2) equalCounts();                    // SAH, bvh.cpp:145-154
+            else {
+                int cnt[12] = {0}; Box bb[12];
+                for (int k = 0; k < 12; ++k) bb[k].reset();
+                for (int i = start; i < end; ++i) {
+                    int b = bucket(cb, items[i].c, dim);
+                    const float *pb = bounds + 6 * (size_t)items[i].id;
+                    cnt[b]++; bb[b].grow(pb); bb[b].grow(pb + 3);
+                }
+                float cost[11];
+                for (int i = 0; i < 11; ++i) {
+                    Box b0, b1; b0.reset(); b1.reset();
+                    int c0 = 0, c1 = 0;
+                    for (int j = 0; j <= i; ++j) { b0.grow(bb[j]); c0 += cnt[j]; }
+                    for (int j = i + 1; j < 12; ++j) { b1.grow(bb[j]); c1 += cnt[j]; }
+                    cost[i] = 1 + (c0 * area(b0) + c1 * area(b1)) / area(all);
+                }
+                float minCost = cost[0]; int minBucket = 0;
+                for (int i = 1; i < 11; ++i) if (cost[i] < minCost) { minCost = cost[i]; minBucket = i; }
+                float leafCost = (float)count;
+                if (count > maxPrims || minCost < leafCost) {
+                    const Box cbc = cb;
+                    Item *m = std::partition(first, last, [&cbc, dim, minBucket](const Item &it) { return bucket(cbc, it.c, dim) <= minBucket; });
+                    mid = (int)(m - items.data());
+                } else leaf = true;
+            }
+        }
         Box box;
-        if (count == 1 || cb.hi[dim] == cb.lo[dim]) {
-            box.reset();
-            node.offset = nSlots; node.nprim = (uint16_t)count;
-            for (int i = start; i < end; ++i) {
-                const float *b = bounds + 6 * (size_t)items[i].id;
-                box.grow(b); box.grow(b + 3);
-                order[nSlots++] = items[i].id;
-            }
+        if (leaf) {
+            box = all;
+            nodes[me].offset = nSlots; nodes[me].nprim = (uint16_t)count;
+            for (int i = start; i < end; ++i) order[nSlots++] = items[i].id;
         } else {
-            float pmid = (cb.lo[dim] + cb.hi[dim]) / 2;
-            Item *first = items.data() + start, *last = items.data() + end;
-            Item *m = std::partition(first, last, [dim, pmid](const Item &it) { return it.c[dim] < pmid; });
-            int mid = (int)(m - items.data());
-            if (mid == start || mid == end) {
-                mid = (start + end) / 2;
-                std::nth_element(first, items.data() + mid, last, [dim](const Item &a, const Item &b) { return a.c[dim] < b.c[dim]; });
-            }
             box = emit(start, mid);
             int32_t second = nNodes;
             Box right = emit(mid, end);
-            box.grow(right);
-            rt_bvh_node &self = nodes[me];   // `node` may dangle only if nodes were reallocated; they are not, but stay explicit
-            self.offset = second; self.nprim = 0; self.axis = (uint8_t)dim;
+            box.grow(right);                                       // InitInterior: Union of the children (bvh.cpp:30-34)
+            nodes[me].offset = second; nodes[me].nprim = 0; nodes[me].axis = (uint8_t)dim;
         }
-        rt_bvh_node &self = nodes[me];
-        for (int k = 0; k < 3; ++k) { self.bmin[k] = box.lo[k]; self.bmax[k] = box.hi[k]; }
+        for (int k = 0; k < 3; ++k) { nodes[me].bmin[k] = box.lo[k]; nodes[me].bmax[k] = box.hi[k]; }
         return box;
     }
 };
@@ -90,10 +133,14 @@ extern "C" {
 
 const char *rt_version(void) { return "raytracing_amd 0.1 (gfx950)"; }
 
-int rt_bvh_build(int32_t n, const float *prim_bounds, rt_bvh_node *nodes_out, int32_t *n_nodes_out, int32_t *order_out) {
+int rt_bvh_build_ex(int32_t n, const float *prim_bounds, int32_t max_prims_in_node, int32_t split_method, rt_bvh_node *nodes_out, int32_t *n_nodes_out,
+                    int32_t *order_out) {
     if (n < 0 || (n > 0 && (!prim_bounds || !nodes_out || !order_out)) || !n_nodes_out) return -1;
+    if (split_method < RT_SPLIT_SAH || split_method > RT_SPLIT_EQUAL_COUNTS || max_prims_in_node < 1) return -1;
     if (n == 0) { *n_nodes_out = 0; return 0; }
     TreeEmitter te;
+    te.maxPrims = std::min(255, (int)max_prims_in_node);      // bvh.cpp:65
+    te.method = split_method == RT_SPLIT_HLBVH ? RT_SPLIT_SAH : split_method;
     te.items.resize(n);
     for (int32_t i = 0; i < n; ++i) {
         const float *b = prim_bounds + 6 * (size_t)i;
@@ -104,6 +151,10 @@ int rt_bvh_build(int32_t n, const float *prim_bounds, rt_bvh_node *nodes_out, in
     te.emit(0, n);
     *n_nodes_out = te.nNodes;
     return 0;
+}
+
+int rt_bvh_build(int32_t n, const float *prim_bounds, rt_bvh_node *nodes_out, int32_t *n_nodes_out, int32_t *order_out) {
+    return rt_bvh_build_ex(n, prim_bounds, 1, RT_SPLIT_MIDDLE, nodes_out, n_nodes_out, order_out);
 }
 
 int rt_prim_bounds(const rt_scene_desc *d, float *out) {

@@ -330,9 +330,9 @@ std::vector<std::shared_ptr<Shape>> CreateTriangleMesh(const Transform *o2w, con
     return tris;
 }
 
-BVHAccel::BVHAccel(std::vector<std::shared_ptr<Primitive>> p, int maxPrimsInNode, SplitMethod splitMethod) {
-    if (maxPrimsInNode != 1 || splitMethod != SplitMethod::Middle)
-        throw std::runtime_error("BVHAccel: only the reference's defaults (maxPrimsInNode=1, SplitMethod::Middle) are implemented");
+BVHAccel::BVHAccel(std::vector<std::shared_ptr<Primitive>> p, int maxPrimsInNode, SplitMethod splitMethod)
+    : maxPrimsInNode(maxPrimsInNode), splitMethod(splitMethod) {
+    if (maxPrimsInNode < 1) throw std::runtime_error("BVHAccel: maxPrimsInNode must be at least 1");
     primitives = std::move(p);
 }
 
@@ -421,7 +421,9 @@ std::unique_ptr<FlatScene> FlattenScene(const Scene &scene) {
         if (rt_prim_bounds(&fs->desc, bounds.data()) != 0) throw std::runtime_error("rt_prim_bounds failed");
         fs->nodes.resize(2 * (size_t)n); fs->prim_order.resize(n);
         int32_t nn = 0;
-        if (rt_bvh_build(n, bounds.data(), fs->nodes.data(), &nn, fs->prim_order.data()) != 0) throw std::runtime_error("rt_bvh_build failed");
+        const BVHAccel *bvh = dynamic_cast<const BVHAccel *>(agg);      // a SimpleAccel gets the default tree
+        int maxPrims = bvh ? bvh->maxPrimsInNode : 1, method = bvh ? (int)bvh->splitMethod : RT_SPLIT_MIDDLE;
+        if (rt_bvh_build_ex(n, bounds.data(), maxPrims, method, fs->nodes.data(), &nn, fs->prim_order.data()) != 0) throw std::runtime_error("rt_bvh_build_ex failed");
         fs->nodes.resize(nn);
         fs->Bind();
     }

@@ -426,12 +426,14 @@ class Aggregate : public Primitive {
 public:
     std::vector<std::shared_ptr<Primitive>> primitives;   // original push order
 };
-// Records the primitive list; the tree itself is built by rt_bvh_build (the reference's
+// Records the primitive list and the build parameters; the tree itself is built by rt_bvh_build_ex (the reference's
 // recursiveBuild decisions, bvh.cpp:86-227) when the scene is flattened.
 class BVHAccel : public Aggregate {
 public:
     enum class SplitMethod { SAH, HLBVH, Middle, EqualCounts };
     BVHAccel(std::vector<std::shared_ptr<Primitive>> p, int maxPrimsInNode = 1, SplitMethod splitMethod = SplitMethod::Middle);
+    int maxPrimsInNode;
+    SplitMethod splitMethod;
 };
 class SimpleAccel : public Aggregate {
 public:

@@ -186,6 +186,27 @@ def golden_for_scene(name, n_rays, img_specs, probe_n=512):
     osc.close(); scene.close()
 
 
+def golden_bvh_variants():
+    """Trees of BVHAccel's other constructor arguments (bvh.h:17-20): SAH with maxPrimsInNode 1 and 4, EqualCounts."""
+    for name in ("cornell", "sphere1", "helmet"):
+        scene = ra.HostScene(name)
+        sbin = os.path.join(TMP, name + ".scene")
+        dump_scene(scene, sbin)
+        out = {}
+        for tag, maxp, method in (("sah1", 1, 0), ("sah4", 4, 0), ("equal", 1, 3), ("hlbvh", 2, 1)):
+            path = os.path.join(TMP, "%s_%s.bvh" % (name, tag))
+            env = dict(os.environ, REF_BVH_MAXPRIMS=str(maxp), REF_BVH_SPLIT=str(method))
+            subprocess.run([DRIVER, "bvh", sbin, path], check=True, env=env)
+            raw = open(path, "rb").read()
+            nn = struct.unpack("<i", raw[:4])[0]
+            out[tag + "_nodes"] = np.frombuffer(raw[4:4 + 32 * nn], dtype=np.uint8).copy()
+            out[tag + "_order"] = np.frombuffer(raw[4 + 32 * nn:], dtype=np.int32).copy()
+            out[tag + "_args"] = np.array([maxp, method], np.int32)
+            print("  ", name, tag, nn, "nodes")
+        np.savez_compressed(os.path.join(GOLD, "ref_bvh_variants_%s.npz" % name), **out)
+        scene.close()
+
+
 def golden_camera():
     rng = np.random.default_rng(3)
     res = {}
@@ -235,6 +256,8 @@ if __name__ == "__main__":
     if not os.path.exists(DRIVER):
         sys.exit("build the reference driver first: make ref")
     only = sys.argv[1:]
+    if not only or "bvhx" in only:
+        golden_bvh_variants()
     if not only or "kat" in only:
         golden_camera(); golden_transform()
     A, B = ("A", 0), ("B", 1 << 20)

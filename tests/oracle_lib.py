@@ -28,6 +28,7 @@ def lib():
         L = C.CDLL(_SO)
         vp, f32p, i32p, u8p, u32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
         L.orc_bvh_build.argtypes = [C.c_int32, f32p, C.POINTER(capi.BvhNode), i32p, i32p]
+        L.orc_bvh_build_ex.argtypes = [C.c_int32, f32p, C.c_int32, C.c_int32, C.POINTER(capi.BvhNode), i32p, i32p]
         L.orc_prim_bounds.argtypes = [C.POINTER(capi.SceneDesc), f32p]
         L.orc_scene_create.argtypes = [C.POINTER(capi.SceneDesc)]; L.orc_scene_create.restype = vp
         L.orc_scene_destroy.argtypes = [vp]; L.orc_scene_destroy.restype = None
@@ -47,13 +48,14 @@ def lib():
     return _lib
 
 
-def bvh_build(bounds):
+def bvh_build(bounds, max_prims=1, method=2):
+    """method: the reference's enum SplitMethod { SAH, HLBVH, Middle, EqualCounts } (bvh.h:17)."""
     bounds = np.ascontiguousarray(bounds, np.float32).reshape(-1, 6)
     n = bounds.shape[0]
     nodes = np.zeros(max(2 * n, 1), capi.BVH_NODE_DTYPE)
     order = np.zeros(max(n, 1), np.int32)
     nn = C.c_int32(0)
-    lib().orc_bvh_build(n, capi.fptr(bounds), nodes.ctypes.data_as(C.POINTER(capi.BvhNode)), C.byref(nn), capi.iptr(order))
+    lib().orc_bvh_build_ex(n, capi.fptr(bounds), max_prims, method, nodes.ctypes.data_as(C.POINTER(capi.BvhNode)), C.byref(nn), capi.iptr(order))
     return nodes[:nn.value].copy(), order[:n].copy()
 
 

@@ -105,6 +105,41 @@ def test_traversal_variants_agree(host_scene, gpu_ctx, monkeypatch):
         assert np.array_equal(base[2].view(np.uint32), other[2].view(np.uint32)) and np.array_equal(base_any, other_any)
 
 
+@pytest.mark.parametrize("tag", ["sah4", "equal"])
+def test_traversal_on_other_trees(tag, host_scene, gpu_ctx, gold_dir):
+    """A tree built with SAH and up to four primitives per leaf (and an EqualCounts tree): leaves with several primitives,
+    a different shape — traversal and a small render still agree with the oracle walking the same tree."""
+    import ctypes as C
+    import oracle_lib as ol
+    hs = host_scene("helmet")
+    g = np.load(os.path.join(gold_dir, "ref_bvh_variants_helmet.npz"))
+    maxp, method = (int(v) for v in g[tag + "_args"])
+    nodes, order = ra.bvh_build(ra.prim_bounds(hs.desc_ptr), maxp, method)
+    assert nodes.tobytes() == g[tag + "_nodes"].tobytes()
+    if tag == "sah4":
+        assert nodes["nprim"].max() > 1
+    d = type(hs.desc).from_buffer_copy(hs.desc)
+    d.n_nodes = len(nodes)
+    d.bvh_nodes = nodes.ctypes.data_as(C.POINTER(ra.capi.BvhNode))
+    d.prim_order = order.ctypes.data_as(C.POINTER(C.c_int32))
+    ds = ra.DeviceScene(gpu_ctx, C.pointer(d)); osc = ol.OracleScene(C.pointer(d))
+    rng = np.random.default_rng(3)
+    n = 200000
+    o = rng.uniform(0, 5, (n, 3)).astype(np.float32)
+    dd = rng.normal(size=(n, 3)).astype(np.float32)
+    dd[:2000, 1] = 0; dd[2000:4000] = [0, 0, 1]
+    tmax = np.full(n, np.inf, np.float32); tmax[5000:9000] = rng.uniform(0, 3, 4000).astype(np.float32)
+    prim, t, b = ds.trace_closest(o, dd, tmax)
+    p2, t2, b2, _, _ = osc.trace_closest(o, dd, tmax)
+    assert np.array_equal(prim, p2) and np.array_equal(t.view(np.uint32), t2.view(np.uint32))
+    assert np.array_equal(ds.trace_any(o, dd, tmax), osc.trace_any(o, dd, tmax))
+    cam = hs.camera(64, 64)
+    img, st = ds.render(cam, ra.make_opts(2, 2))
+    ref, _ = osc.render(cam, ra.make_opts(2, 2), mode=1)
+    assert _rel_close(img, ref, 2e-3).mean() > 0.995
+    ds.close(); osc.close()
+
+
 def test_trace_edge_cases(device_scene):
     ds = device_scene("cornell")
     e = np.zeros((0, 3), np.float32)

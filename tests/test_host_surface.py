@@ -55,6 +55,22 @@ def test_product_bvh_builder_reproduces_reference_tree(name, host_scene, gold_di
     assert nodes.tobytes() == g["nodes"].tobytes() and np.array_equal(order, g["order"])
 
 
+@pytest.mark.parametrize("name", ["cornell", "sphere1", "helmet"])
+def test_product_bvh_builder_other_split_methods(name, host_scene, gold_dir):
+    """rt_bvh_build_ex: SAH / EqualCounts / HLBVH trees byte-identical to the reference's BVHAccel for the same arguments."""
+    g = np.load(os.path.join(gold_dir, "ref_bvh_variants_%s.npz" % name))
+    bounds = ra.prim_bounds(host_scene(name).desc_ptr)
+    for tag in ("sah1", "sah4", "equal", "hlbvh"):
+        maxp, method = (int(v) for v in g[tag + "_args"])
+        nodes, order = ra.bvh_build(bounds, maxp, method)
+        assert nodes.tobytes() == g[tag + "_nodes"].tobytes(), tag
+        assert np.array_equal(order, g[tag + "_order"]), tag
+    with pytest.raises(RuntimeError):
+        ra.bvh_build(bounds, 0, 2)
+    with pytest.raises(RuntimeError):
+        ra.bvh_build(bounds, 1, 7)
+
+
 def test_bvh_builder_edge_cases():
     rng = np.random.default_rng(0)
     import oracle_lib as ol
