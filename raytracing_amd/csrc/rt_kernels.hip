@@ -34,8 +34,10 @@
 
 #define RT_NUM_CLASSES 6
 #define RT_BATCH_STACK 32       // LDS ring depth of the batch trace kernels (deep trees)
-#define RT_SEG_BLOCKS 1024      // persistent grid of every wavefront kernel == number of queue segments
+#define RT_SEG_BLOCKS 1280      // most queue segments = largest grid of the wavefront kernels (five blocks per CU)
 #define RT_SEG_PER_THREAD (RT_SEG_BLOCKS / RT_BLOCK)
+// The number of segments in use is the grid size of the frame kernels (gridDim.x, a multiple of RT_BLOCK): 1280 when every
+// kernel of the frame fits five blocks on a CU, 1024 when the persistent-lane kernels (four per CU) take part.
 
 // Queues are segmented: block b of a producer kernel appends only to segment b (positions
 // [b*segcap, b*segcap + count[b])) using a block-local LDS counter, and publishes count[b] with a plain store when it
@@ -72,12 +74,13 @@ __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi
 __device__ __forceinline__ uint32_t prefix_in_mask(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-// Exclusive prefix sum of RT_SEG_BLOCKS segment counts into s_prefix[0..RT_SEG_BLOCKS] (last entry = total).
+// Exclusive prefix sum of the gridDim.x segment counts into s_prefix[0..gridDim.x] (last entry = total).
 __device__ __forceinline__ uint32_t segment_prefix(const uint32_t *__restrict__ counts, uint32_t *s_prefix, uint32_t *s_wave) {
     uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t per = gridDim.x / RT_BLOCK;     // counts per thread, at most RT_SEG_PER_THREAD
     uint32_t v[RT_SEG_PER_THREAD], sum = 0;
 #pragma unroll
-    for (int k = 0; k < RT_SEG_PER_THREAD; ++k) { v[k] = counts[t * RT_SEG_PER_THREAD + k]; sum += v[k]; }
+    for (int k = 0; k < RT_SEG_PER_THREAD; ++k) { v[k] = (uint32_t)k < per ? counts[t * per + k] : 0u; sum += v[k]; }
     uint32_t incl = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { uint32_t y = __shfl_up(incl, off); if (lane >= (uint32_t)off) incl += y; }
@@ -87,14 +90,14 @@ __device__ __forceinline__ uint32_t segment_prefix(const uint32_t *__restrict__ 
     for (uint32_t w = 0; w < wave; ++w) base += s_wave[w];
     uint32_t run = base + incl - sum;
 #pragma unroll
-    for (int k = 0; k < RT_SEG_PER_THREAD; ++k) { s_prefix[t * RT_SEG_PER_THREAD + k] = run; run += v[k]; }
-    if (t == RT_BLOCK - 1) s_prefix[RT_SEG_BLOCKS] = run;
+    for (int k = 0; k < RT_SEG_PER_THREAD; ++k) if ((uint32_t)k < per) { s_prefix[t * per + k] = run; run += v[k]; }
+    if (t == RT_BLOCK - 1) s_prefix[gridDim.x] = run;
     __syncthreads();
-    return s_prefix[RT_SEG_BLOCKS];
+    return s_prefix[gridDim.x];
 }
 // This block's share [lo, hi) of `total` concatenated items (multiples of the wave size).
 __device__ __forceinline__ void block_share(uint32_t total, uint32_t &lo, uint32_t &hi) {
-    uint32_t share = (total + RT_SEG_BLOCKS - 1) / RT_SEG_BLOCKS;
+    uint32_t share = (total + gridDim.x - 1) / gridDim.x;
     share = (share + RT_WAVE - 1) & ~(uint32_t)(RT_WAVE - 1);
     uint64_t l = (uint64_t)blockIdx.x * share;
     lo = (uint32_t)(l < total ? l : total);
@@ -102,7 +105,7 @@ __device__ __forceinline__ void block_share(uint32_t total, uint32_t &lo, uint32
 }
 // Segment that holds concatenated index g (s_prefix[s] <= g < s_prefix[s+1]); g < total.
 __device__ __forceinline__ uint32_t segment_of(const uint32_t *s_prefix, uint32_t g) {
-    uint32_t lo = 0, hi = RT_SEG_BLOCKS;   // invariant: s_prefix[lo] <= g < s_prefix[hi]
+    uint32_t lo = 0, hi = gridDim.x;   // invariant: s_prefix[lo] <= g < s_prefix[hi]
     while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (s_prefix[mid] <= g) lo = mid; else hi = mid; }
     return lo;
 }
@@ -1447,8 +1450,8 @@ static void bind_queue(PathQueue &q, void *base, size_t cap) {
 extern "C++" {
 template <int MAT>
 static void launch_shade(rt_scene *s, const RenderParams &rp, int bounce, const PathQueue &q, const PathQueue &qn, const HitBuf &hb, uint32_t cap,
-                         uint32_t segcap, const ShadowQueue &sq) {
-    hipLaunchKernelGGL((k_shade<MAT>), dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p, cap,
+                         uint32_t segcap, const ShadowQueue &sq, int nseg) {
+    hipLaunchKernelGGL((k_shade<MAT>), dim3(nseg), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p, cap,
                        segcap, sq, (BounceCounts *)s->d_counters.p);
 }
 }  // extern "C++"
@@ -1476,11 +1479,16 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     int spb = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(S, 1), pool / npix));
     size_t n_pass = npix * (size_t)spb;
     if (n_pass >= (1ull << 31)) { set_error(ctx, "rt_render: pass too large"); return -1; }
+    // queue segments = grid of every frame kernel: five blocks per CU unless the persistent-lane kernels (four per CU) run
+    const int ncu = std::max(1, ctx->n_cu);
+    const bool small_tree = this_->dev.n_nodes <= 4096;
+    int nseg = env_int("RT_AMD_FRAME_BLOCKS_PER_CU", small_tree ? 5 : 4) * ncu;
+    nseg = std::max(RT_BLOCK, std::min(RT_SEG_BLOCKS, nseg / RT_BLOCK * RT_BLOCK));
     // segment capacity: a block's share of the pass, plus room for the rounding of every class kernel's share
-    size_t share = (n_pass + RT_SEG_BLOCKS - 1) / RT_SEG_BLOCKS;
+    size_t share = (n_pass + nseg - 1) / nseg;
     share = (share + RT_WAVE - 1) & ~(size_t)(RT_WAVE - 1);
     size_t segcap = share + (size_t)RT_WAVE * RT_NUM_CLASSES;
-    size_t cap = segcap * RT_SEG_BLOCKS;
+    size_t cap = segcap * nseg;
     if (cap >= (1ull << 31)) { set_error(ctx, "rt_render: pass too large"); return -1; }
     if (cap > this_->ws_cap) {
         HIP_OK(this_->d_q[0].alloc(11 * cap * 4)); HIP_OK(this_->d_q[1].alloc(11 * cap * 4));
@@ -1504,7 +1512,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     BounceStats *bstats = (BounceStats *)((char *)this_->d_counters.p + counts_bytes);
     float4 *lbuf = (float4 *)this_->d_lbuf.p;
     int grid = persistent_grid(ctx);
-    if (RT_SEG_BLOCKS * RT_BLOCK > grid * RT_BLOCK) { set_error(ctx, "rt_render: spill area smaller than the wavefront grid"); return -1; }
+    if (nseg * RT_BLOCK > grid * RT_BLOCK) { set_error(ctx, "rt_render: spill area smaller than the wavefront grid"); return -1; }
 
     RenderParams rp; memset(&rp, 0, sizeof(rp));
     memcpy(rp.r2c, cam->raster_to_camera, 64); memcpy(rp.c2w, cam->camera_to_world, 64);
@@ -1524,49 +1532,49 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     // rays of a wave take about the same number of steps: always on small trees, and for camera rays on large ones;
     // persistent lanes win on deep trees once the rays are incoherent.  Measured, Msamples/s: Cornell 1174 round-based
     // vs 1002 persistent; spheres 3445 vs 3169; helmet 273 round-based, 328 persistent, 346 with only bounce 0 round-based.
-    const int round_bounces = env_int("RT_AMD_FRAME_ROUND_BOUNCES", this_->dev.n_nodes <= 4096 ? 1 << 20 : 1);
+    const int round_bounces = env_int("RT_AMD_FRAME_ROUND_BOUNCES", small_tree ? 1 << 20 : 1);
     const int round_pairs = (this_->interior_depth <= 8 && env_int("RT_AMD_ROUND_PAIRS", 1)) ? 1 : 0;
     const int round_quads = (this_->dev.quads && env_int("RT_AMD_ROUND_PAIRS", 1)) ? 1 : 0;
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
         int cur = std::min(spb, o->sample_end - s0);
         rp.spb = cur; rp.sample0 = s0; rp.n_paths = (uint32_t)(npix * (size_t)cur);
         HIP_OK(hipMemsetAsync(bstats, 0, stats_bytes, ctx->stream));
-        hipLaunchKernelGGL(k_raygen, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, rp, q[0], useg, lbuf, counts);
+        hipLaunchKernelGGL(k_raygen, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, rp, q[0], useg, lbuf, counts);
         int cq = 0;
         for (int b = 0; b <= o->max_depth; ++b) {
             if (frame_old || b < round_bounces) {
                 if (lds_scene)
-                    hipLaunchKernelGGL(k_extend<true>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
+                    hipLaunchKernelGGL(k_extend<true>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
                                        ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, round_pairs);
                 else
-                    hipLaunchKernelGGL(k_extend<false>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
+                    hipLaunchKernelGGL(k_extend<false>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
                                        ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, round_quads);
             } else if (walk_mode == RT_WALK_QUADS)
-                hipLaunchKernelGGL(k_extend_pl<RT_WALK_QUADS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
+                hipLaunchKernelGGL(k_extend_pl<RT_WALK_QUADS>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
                                    (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
             else
-                hipLaunchKernelGGL(k_extend_pl<RT_WALK_PAIRS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
+                hipLaunchKernelGGL(k_extend_pl<RT_WALK_PAIRS>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
                                    (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
             if (b < o->max_depth) {
-                if (this_->classes[RT_MAT_MATTE]) launch_shade<RT_MAT_MATTE>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
-                if (this_->classes[RT_MAT_MIRROR]) launch_shade<RT_MAT_MIRROR>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
-                if (this_->classes[RT_MAT_GLASS]) launch_shade<RT_MAT_GLASS>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
-                if (this_->classes[RT_MAT_METAL]) launch_shade<RT_MAT_METAL>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
-                if (this_->classes[RT_MAT_PLASTIC]) launch_shade<RT_MAT_PLASTIC>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
-                if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq);
+                if (this_->classes[RT_MAT_MATTE]) launch_shade<RT_MAT_MATTE>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg);
+                if (this_->classes[RT_MAT_MIRROR]) launch_shade<RT_MAT_MIRROR>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg);
+                if (this_->classes[RT_MAT_GLASS]) launch_shade<RT_MAT_GLASS>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg);
+                if (this_->classes[RT_MAT_METAL]) launch_shade<RT_MAT_METAL>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg);
+                if (this_->classes[RT_MAT_PLASTIC]) launch_shade<RT_MAT_PLASTIC>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg);
+                if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg);
                 if (this_->dev.n_lights > 0) {
                     if (frame_old || b < round_bounces) {
                         if (lds_scene)
-                            hipLaunchKernelGGL(k_shadow<true>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
+                            hipLaunchKernelGGL(k_shadow<true>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
                                                (int *)this_->d_spill.p, round_pairs);
                         else
-                            hipLaunchKernelGGL(k_shadow<false>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
+                            hipLaunchKernelGGL(k_shadow<false>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
                                                (int *)this_->d_spill.p, round_quads);
                     } else if (walk_mode == RT_WALK_QUADS)       // the hit buffer's slot array is free once the shading kernels are done
-                        hipLaunchKernelGGL(k_shadow_pl<RT_WALK_QUADS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, hb.slot, useg, lbuf,
+                        hipLaunchKernelGGL(k_shadow_pl<RT_WALK_QUADS>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, hb.slot, useg, lbuf,
                                            counts, bstats, (int *)this_->d_spill.p);
                     else
-                        hipLaunchKernelGGL(k_shadow_pl<RT_WALK_PAIRS>, dim3(RT_SEG_BLOCKS), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, hb.slot, useg, lbuf,
+                        hipLaunchKernelGGL(k_shadow_pl<RT_WALK_PAIRS>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, hb.slot, useg, lbuf,
                                            counts, bstats, (int *)this_->d_spill.p);
                 }
             }
