@@ -126,27 +126,67 @@ def traversal_roofline(ctx, n_tris, n_rays, repeats, bounces=4):
     return out
 
 
+def _time_reference(scene, cores):
+    """The reference's own code (its core/*.cpp compiled from source into oracle/_ref/ref_driver, see oracle/Makefile) rendering
+    the same Cornell scene on the host cores: processes instead of threads, because its integrator keeps state in globals."""
+    import subprocess
+    import tempfile
+    import ref_io
+    driver = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if not os.path.exists(driver):
+        return None
+    tmp = tempfile.mkdtemp(prefix="rt_bench_")
+    sbin, cbin, out = (os.path.join(tmp, f) for f in ("cornell.scene", "cam.bin", "img.f32"))
+    ref_io.dump_scene(scene, sbin, tmp)
+    open(cbin, "wb").write(ref_io.cam_spec("cornell", W, H))
+
+    def run(sx, sy):
+        t0 = time.time()
+        subprocess.run([driver, "render", sbin, cbin, str(sx), str(sy), str(MAX_DEPTH), "0", str(cores), out], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return time.time() - t0
+
+    try:
+        dt = run(2, 2); spp = 4
+        for sx, sy in ((16, 16), (16, 8), (8, 8), (8, 4), (4, 4)):
+            if dt / 4 * sx * sy <= 25.0:
+                spp = sx * sy; dt = run(sx, sy)
+                break
+    except Exception:
+        return None
+    return {"value": round(W * H * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "reference",
+            "sample": "Cornell %dx%d @ %d spp (%.1f s) by the reference's own sources compiled here (oracle/_ref/ref_driver), %d processes" % (W, H, spp, dt, cores)}
+
+
 def cpu_baseline(scene):
-    """The oracle's recursive per-pixel renderer on the host cores: Cornell 800x800 at a few spp (cost is linear in spp)."""
+    """CPU side of the comparison on this host's cores, Cornell 800x800 at a few spp (cost is linear in spp): the reference
+    itself when its build is present, else the oracle's restatement of its recursive per-pixel renderer (which is also timed,
+    on a smaller sample, as a cross-check of the two)."""
     import oracle_lib as ol
     cores = min(os.cpu_count() or 1, 16)
+    ref = _time_reference(scene, cores)
     osc = ol.OracleScene(scene.desc_ptr)
     cam = scene.camera(W, H)
     t0 = time.time()
     osc.render(cam, ra.make_opts(2, 2), mode=0, threads=cores)
     dt = time.time() - t0
     spp = 4
-    # bound the sample to roughly 10-30 s of CPU work: the largest strata grid whose projected time stays under 25 s
+    # bound the sample: the largest strata grid whose projected time stays under 25 s (8 s when it is only the cross-check)
+    budget = 8.0 if ref else 25.0
     for sx, sy in ((16, 16), (16, 8), (8, 8), (8, 4), (4, 4)):
-        if dt / 4 * sx * sy <= 25.0:
+        if dt / 4 * sx * sy <= budget:
             spp = sx * sy
             t0 = time.time()
             osc.render(cam, ra.make_opts(sx, sy), mode=0, threads=cores)
             dt = time.time() - t0
             break
     osc.close()
-    return {"value": round(W * H * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "Cornell 800x800 @ %d spp (%.1f s); CPU restatement of the reference's recursive renderer, bit-exact with it" % (spp, dt)}
+    port = {"value": round(W * H * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "Cornell %dx%d @ %d spp (%.1f s); CPU restatement of the reference's recursive renderer, bit-exact with it" % (W, H, spp, dt)}
+    if ref:
+        ref["port_cross_check"] = port
+        return ref
+    return port
 
 
 def main():

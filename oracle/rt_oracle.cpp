@@ -1222,7 +1222,8 @@ int orc_render(orc_scene *h, const rt_camera *cam, const rt_render_opts *opts, i
     std::atomic<int64_t> next(0);
     std::vector<PathCounters> pcs(threads); std::vector<uint64_t> nsamp(threads, 0);
     auto work = [&](int tid) {
-        PathCounters &pc = pcs[tid]; pc.closest = pc.shadow = 0;
+        PathCounters pc; pc.closest = pc.shadow = 0;      // thread-local: neighbours in `pcs` / `nsamp` share cache lines
+        uint64_t ns = 0;
         const int64_t grain = 256;
         while (true) {
             int64_t lo = next.fetch_add(grain); if (lo >= npix) break;
@@ -1241,7 +1242,7 @@ int orc_render(orc_scene *h, const rt_camera *cam, const rt_render_opts *opts, i
                             Ray r = GenerateRay(*cam, (Float)i + fx, (Float)j + fy);
                             bool spec = false;
                             col = col + Li_re(sc, r, smp, 0, opts->max_depth, &spec, &pc);
-                            nsamp[tid]++;
+                            ns++;
                         }
                     } while (smp.StartNextSample());
                 } else {
@@ -1252,12 +1253,13 @@ int orc_render(orc_scene *h, const rt_camera *cam, const rt_render_opts *opts, i
                         Ray r = GenerateRay(*cam, (Float)i + fx, (Float)j + fy);
                         bool spec = false;
                         col = col + Li_re(sc, r, smp, 0, opts->max_depth, &spec, &pc);
-                        nsamp[tid]++;
+                        ns++;
                     }
                 }
                 out_sum_rgb[3 * pos] = col[0]; out_sum_rgb[3 * pos + 1] = col[1]; out_sum_rgb[3 * pos + 2] = col[2];
             }
         }
+        pcs[tid] = pc; nsamp[tid] = ns;
     };
     std::vector<std::thread> pool;
     for (int t = 0; t < threads; ++t) pool.emplace_back(work, t);
