@@ -56,6 +56,7 @@ struct DevScene {
     const float4 *quads;      // 8 x float4 per even-depth interior node (rt_traverse2.h); null when the tree does not qualify
     int n_quads, quad_stack_cap;
     uint32_t pad;
+    int n_materials, n_textures;
 };
 
 struct F3 { float x, y, z; };

@@ -584,10 +584,37 @@ __device__ __forceinline__ void build_plastic_gloss(const DevScene &sc, const De
     l.dist.ax = fmaxf(0.001f, rough); l.dist.ay = fmaxf(0.001f, rough);
 }
 
-template <int MAT>
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, RenderParams rp, int bounce, PathQueue q, PathQueue qn, HitBuf hb, const uint32_t *cls_list,
+// Small scenes: every table the shading code follows a slot through (slot -> material -> textures, slot -> vertices /
+// frame / uv, lights) is copied to LDS, so the chain of dependent reads per path stays on the CU.
+#define RT_LDS_TAB_SLOTS RT_LDS_SCENE_SLOTS
+#define RT_LDS_TAB_MATERIALS 16
+#define RT_LDS_TAB_TEXTURES 32
+#define RT_LDS_TAB_LIGHTS 8
+__device__ __forceinline__ void copy_words_to_lds(void *dst, const void *src, int bytes) {
+    uint32_t *d = (uint32_t *)dst; const uint32_t *g = (const uint32_t *)src;
+    for (int i = threadIdx.x; i < bytes / 4; i += RT_BLOCK) d[i] = g[i];
+}
+
+template <int MAT, bool LDS_TABLES>
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc_in, RenderParams rp, int bounce, PathQueue q, PathQueue qn, HitBuf hb, const uint32_t *cls_list,
                                                      uint32_t cap, uint32_t segcap, ShadowQueue sq, BounceCounts *counts) {
     __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE], s_out[2];
+    __shared__ float4 s_slots[LDS_TABLES ? 3 * RT_LDS_TAB_SLOTS : 1], s_frames[LDS_TABLES ? 3 * RT_LDS_TAB_SLOTS : 1];
+    __shared__ float s_uv[LDS_TABLES ? 6 * RT_LDS_TAB_SLOTS : 1];
+    __shared__ int s_slot_mat[LDS_TABLES ? RT_LDS_TAB_SLOTS : 1];
+    __shared__ DevMaterial s_mats[LDS_TABLES ? RT_LDS_TAB_MATERIALS : 1];
+    __shared__ DevTexture s_tex[LDS_TABLES ? RT_LDS_TAB_TEXTURES : 1];
+    __shared__ DevLight s_lights[LDS_TABLES ? RT_LDS_TAB_LIGHTS : 1];
+    DevScene sc = sc_in;
+    if (LDS_TABLES) {      // the barriers of segment_prefix below order these copies before their use
+        copy_words_to_lds(s_slots, sc_in.slots, 48 * sc_in.n_slots); copy_words_to_lds(s_frames, sc_in.frames, 48 * sc_in.n_slots);
+        copy_words_to_lds(s_uv, sc_in.slot_uv, 24 * sc_in.n_slots); copy_words_to_lds(s_slot_mat, sc_in.slot_material, 4 * sc_in.n_slots);
+        copy_words_to_lds(s_mats, sc_in.materials, (int)sizeof(DevMaterial) * sc_in.n_materials);
+        copy_words_to_lds(s_tex, sc_in.textures, (int)sizeof(DevTexture) * sc_in.n_textures);
+        copy_words_to_lds(s_lights, sc_in.lights, (int)sizeof(DevLight) * sc_in.n_lights);
+        sc.slots = s_slots; sc.frames = s_frames; sc.slot_uv = s_uv; sc.slot_material = s_slot_mat; sc.materials = s_mats; sc.textures = s_tex;
+        sc.lights = s_lights;
+    }
     BounceCounts *bc = counts + bounce;
     const uint32_t *list = cls_list + (size_t)MAT * cap;
     // continue this block's segments where the previous class kernel of this bounce left them
@@ -1325,7 +1352,7 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     D.nodes = (const float4 *)sc->d_nodes.p; D.slots = (const float4 *)sc->d_slots.p; D.frames = (const float4 *)sc->d_frames.p;
     D.slot_uv = (const float *)sc->d_uv.p; D.spheres = (const float *)sc->d_spheres.p; D.slot_material = (const int *)sc->d_slot_mat.p;
     D.slot_light = (const int *)sc->d_slot_light.p; D.materials = (const DevMaterial *)sc->d_mats.p; D.textures = (const DevTexture *)sc->d_tex.p;
-    D.lights = (const DevLight *)sc->d_lights.p; D.n_nodes = nn; D.n_slots = d->n_prims; D.n_lights = d->n_lights; D.pad = 0;
+    D.lights = (const DevLight *)sc->d_lights.p; D.n_nodes = nn; D.n_slots = d->n_prims; D.n_lights = d->n_lights; D.pad = 0; D.n_materials = d->n_materials; D.n_textures = d->n_textures;
     D.pairs = (const float4 *)sc->d_pairs.p; D.n_pairs = n_pairs;
     memcpy(D.root_box, sc->nodes[0].bmin, 12); memcpy(D.root_box + 3, sc->nodes[0].bmax, 12);
     D.root_info = childInfo(0);
@@ -1451,8 +1478,14 @@ extern "C++" {
 template <int MAT>
 static void launch_shade(rt_scene *s, const RenderParams &rp, int bounce, const PathQueue &q, const PathQueue &qn, const HitBuf &hb, uint32_t cap,
                          uint32_t segcap, const ShadowQueue &sq, int nseg) {
-    hipLaunchKernelGGL((k_shade<MAT>), dim3(nseg), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p, cap,
-                       segcap, sq, (BounceCounts *)s->d_counters.p);
+    const bool lds_tables = s->dev.n_slots <= RT_LDS_TAB_SLOTS && s->dev.n_materials <= RT_LDS_TAB_MATERIALS && s->dev.n_textures <= RT_LDS_TAB_TEXTURES &&
+                            s->dev.n_lights <= RT_LDS_TAB_LIGHTS && !env_int("RT_AMD_SHADE_GLOBAL_TABLES", 0);
+    if (lds_tables)
+        hipLaunchKernelGGL((k_shade<MAT, true>), dim3(nseg), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p, cap,
+                           segcap, sq, (BounceCounts *)s->d_counters.p);
+    else
+        hipLaunchKernelGGL((k_shade<MAT, false>), dim3(nseg), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p, cap,
+                           segcap, sq, (BounceCounts *)s->d_counters.p);
 }
 }  // extern "C++"
 
