@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(_HERE, "lib")
+LIB_DIR = os.environ.get("RT_AMD_LIB_DIR") or os.path.join(_HERE, "lib")   # override: A/B builds of the kernels
 
 
 class BvhNode(C.Structure):

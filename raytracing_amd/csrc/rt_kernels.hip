@@ -36,6 +36,7 @@
 #define RT_BATCH_STACK 32       // LDS ring depth of the batch trace kernels (deep trees)
 #define RT_SEG_BLOCKS 1280      // most queue segments = largest grid of the wavefront kernels (five blocks per CU)
 #define RT_SEG_PER_THREAD (RT_SEG_BLOCKS / RT_BLOCK)
+#define RT_FRAME_RING 8         // LDS ring entries per lane (node, tMin) of the frame kernels
 // The number of segments in use is the grid size of the frame kernels (gridDim.x, a multiple of RT_BLOCK): 1280 when every
 // kernel of the frame fits five blocks on a CU, 1024 when the persistent-lane kernels (four per CU) take part.
 
@@ -293,6 +294,12 @@ __device__ __forceinline__ void stage_scene_lds(const DevScene &sc, float4 *s_no
     for (int i = threadIdx.x; i < 3 * sc.n_slots; i += RT_BLOCK) s_slots[i] = sc.slots[i];
 }
 
+// Pair records of a small scene into LDS: the k-th float4 of record r goes to s_pairs[k * 64 + r], so that consecutive records
+// fall into different banks (lane_walk<.., KSTRIDE = 64>, rt_traverse2.h).
+__device__ __forceinline__ void stage_pairs_lds(const DevScene &sc, float4 *s_pairs) {
+    for (int i = threadIdx.x; i < 4 * sc.n_pairs; i += RT_BLOCK) s_pairs[(i & 3) * (RT_LDS_SCENE_NODES / 2) + (i >> 2)] = sc.pairs[i];
+}
+
 template <bool LDS_SCENE>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
                                                       uint32_t segcap, float4 *lbuf, BounceCounts *counts, BounceStats *stats, int *spill, int fast_walk) {
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, RenderParams r
     // fast_walk on an LDS scene: the LDS copy holds pair records (k-th float4 of record r at s_nodes[k * 64 + r]) instead of nodes; the int
     // stack area then carries (node, tMin) entries for 8 levels, which the host guarantees to be enough
     if (LDS_SCENE && fast_walk) {
-        for (int i = threadIdx.x; i < 4 * sc.n_pairs; i += RT_BLOCK) s_nodes[(i & 3) * (RT_LDS_SCENE_NODES / 2) + (i >> 2)] = sc.pairs[i];
+        stage_pairs_lds(sc, s_nodes);
         for (int i = threadIdx.x; i < 3 * sc.n_slots; i += RT_BLOCK) s_slots[i] = sc.slots[i];
     } else if (LDS_SCENE) stage_scene_lds(sc, s_nodes, s_slots);
     PairStackT<8, false> pst; pst.lds_i = &s_stack[threadIdx.x]; pst.lds_t = (float *)&s_stack[8 * RT_BLOCK + threadIdx.x]; pst.reset();
@@ -595,26 +602,39 @@ __device__ __forceinline__ void copy_words_to_lds(void *dst, const void *src, in
     for (int i = threadIdx.x; i < bytes / 4; i += RT_BLOCK) d[i] = g[i];
 }
 
-template <int MAT, bool LDS_TABLES>
+// FUSE (LDS_TABLES scenes whose tree also fits the LDS walk): the shadow ray of next-event estimation is traced here, out of an
+// LDS copy of the pair records, instead of going through the shadow queue to k_shadow; the unoccluded light is added to
+// the path's radiance slot at once.  The tables live in dynamic LDS sized to the scene (shade_lds_bytes).
+template <int MAT, bool LDS_TABLES, bool FUSE>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc_in, RenderParams rp, int bounce, PathQueue q, PathQueue qn, HitBuf hb, const uint32_t *cls_list,
-                                                     uint32_t cap, uint32_t segcap, ShadowQueue sq, BounceCounts *counts) {
+                                                     uint32_t cap, uint32_t segcap, ShadowQueue sq, BounceCounts *counts, float4 *lbuf, BounceStats *stats) {
+    static_assert(!FUSE || LDS_TABLES, "the fused shadow walk needs the LDS tables");
     __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE], s_out[2];
-    __shared__ float4 s_slots[LDS_TABLES ? 3 * RT_LDS_TAB_SLOTS : 1], s_frames[LDS_TABLES ? 3 * RT_LDS_TAB_SLOTS : 1];
-    __shared__ float s_uv[LDS_TABLES ? 6 * RT_LDS_TAB_SLOTS : 1];
-    __shared__ int s_slot_mat[LDS_TABLES ? RT_LDS_TAB_SLOTS : 1];
-    __shared__ DevMaterial s_mats[LDS_TABLES ? RT_LDS_TAB_MATERIALS : 1];
-    __shared__ DevTexture s_tex[LDS_TABLES ? RT_LDS_TAB_TEXTURES : 1];
-    __shared__ DevLight s_lights[LDS_TABLES ? RT_LDS_TAB_LIGHTS : 1];
+    extern __shared__ float4 s_dyn[];
+    __shared__ float4 s_pairs[FUSE ? 2 * RT_LDS_SCENE_NODES : 1];
+    __shared__ int s_stack[FUSE ? 2 * RT_FRAME_RING * RT_BLOCK : 1];
     DevScene sc = sc_in;
+    const float4 *s_slots = s_dyn;
     if (LDS_TABLES) {      // the barriers of segment_prefix below order these copies before their use
-        copy_words_to_lds(s_slots, sc_in.slots, 48 * sc_in.n_slots); copy_words_to_lds(s_frames, sc_in.frames, 48 * sc_in.n_slots);
-        copy_words_to_lds(s_uv, sc_in.slot_uv, 24 * sc_in.n_slots); copy_words_to_lds(s_slot_mat, sc_in.slot_material, 4 * sc_in.n_slots);
-        copy_words_to_lds(s_mats, sc_in.materials, (int)sizeof(DevMaterial) * sc_in.n_materials);
-        copy_words_to_lds(s_tex, sc_in.textures, (int)sizeof(DevTexture) * sc_in.n_textures);
-        copy_words_to_lds(s_lights, sc_in.lights, (int)sizeof(DevLight) * sc_in.n_lights);
-        sc.slots = s_slots; sc.frames = s_frames; sc.slot_uv = s_uv; sc.slot_material = s_slot_mat; sc.materials = s_mats; sc.textures = s_tex;
-        sc.lights = s_lights;
+        const int ns = sc_in.n_slots;
+        float4 *t_slots = s_dyn, *t_frames = t_slots + 3 * ns;
+        DevTexture *t_tex = (DevTexture *)(t_frames + 3 * ns);
+        DevLight *t_lights = (DevLight *)(t_tex + sc_in.n_textures);
+        DevMaterial *t_mats = (DevMaterial *)(t_lights + sc_in.n_lights);
+        float *t_uv = (float *)(t_mats + sc_in.n_materials);
+        int *t_slot_mat = (int *)(t_uv + 6 * ns);
+        copy_words_to_lds(t_slots, sc_in.slots, 48 * ns); copy_words_to_lds(t_frames, sc_in.frames, 48 * ns);
+        copy_words_to_lds(t_uv, sc_in.slot_uv, 24 * ns); copy_words_to_lds(t_slot_mat, sc_in.slot_material, 4 * ns);
+        copy_words_to_lds(t_mats, sc_in.materials, (int)sizeof(DevMaterial) * sc_in.n_materials);
+        copy_words_to_lds(t_tex, sc_in.textures, (int)sizeof(DevTexture) * sc_in.n_textures);
+        copy_words_to_lds(t_lights, sc_in.lights, (int)sizeof(DevLight) * sc_in.n_lights);
+        sc.slots = t_slots; sc.frames = t_frames; sc.slot_uv = t_uv; sc.slot_material = t_slot_mat; sc.materials = t_mats; sc.textures = t_tex;
+        sc.lights = t_lights;
     }
+    if (FUSE)              // pair records, k-th float4 of record r at s_pairs[k * 64 + r] (the layout k_extend / k_shadow walk)
+        stage_pairs_lds(sc_in, s_pairs);
+    PairStackT<RT_FRAME_RING, false> pst; pst.lds_i = &s_stack[FUSE ? threadIdx.x : 0]; pst.lds_t = (float *)&s_stack[FUSE ? RT_FRAME_RING * RT_BLOCK + threadIdx.x : 0]; pst.reset();
+    uint32_t n_shadow_rays = 0;
     BounceCounts *bc = counts + bounce;
     const uint32_t *list = cls_list + (size_t)MAT * cap;
     // continue this block's segments where the previous class kernel of this bounce left them
@@ -751,10 +771,25 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc_in, RenderParams
                 }
             }
         }
-        uint32_t spos = seg_base + block_append(has_shadow, &s_out[0]);
-        if (has_shadow) {
-            sq.id[spos] = id; sq.ox[spos] = so.x; sq.oy[spos] = so.y; sq.oz[spos] = so.z; sq.dx[spos] = sd.x; sq.dy[spos] = sd.y; sq.dz[spos] = sd.z;
-            sq.cr[spos] = sc3.x; sq.cg[spos] = sc3.y; sq.cb[spos] = sc3.z;
+        if (FUSE) {            // bvh.cpp:284-320 on the spot; tMax = 1 - ShadowEpsilon (interaction.h:27-32)
+            n_shadow_rays += (uint32_t)__popcll(__ballot(has_shadow));
+            bool lit = false;
+            if (has_shadow) {
+                LaneTrav L = {};
+                trace_one<true, RT_LDS_SCENE_NODES / 2>(sc_in, s_pairs, s_slots, so, sd, 1.f - 0.0001f, pst, L);
+                lit = !L.found;
+            }
+            if (lit) {
+                float4 Lr = lbuf[id];
+                Lr.x += sc3.x; Lr.y += sc3.y; Lr.z += sc3.z;
+                lbuf[id] = Lr;
+            }
+        } else {
+            uint32_t spos = seg_base + block_append(has_shadow, &s_out[0]);
+            if (has_shadow) {
+                sq.id[spos] = id; sq.ox[spos] = so.x; sq.oy[spos] = so.y; sq.oz[spos] = so.z; sq.dx[spos] = sd.x; sq.dy[spos] = sd.y; sq.dz[spos] = sd.z;
+                sq.cr[spos] = sc3.x; sq.cg[spos] = sc3.y; sq.cb[spos] = sc3.z;
+            }
         }
         uint32_t npos = seg_base + block_append(has_next, &s_out[1]);
         if (has_next) {
@@ -764,6 +799,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc_in, RenderParams
     }
     __syncthreads();
     if (threadIdx.x == 0) { bc->shadow[blockIdx.x] = s_out[0]; counts[bounce + 1].queue[blockIdx.x] = s_out[1]; }
+    if (FUSE && (threadIdx.x & (RT_WAVE - 1)) == 0 && n_shadow_rays) atomicAdd(&stats[bounce].n_shadow, n_shadow_rays);   // statistics only
 }
 
 // ------------------------------------------------------------------ shadow --
@@ -775,7 +811,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, Sh
     // fast_walk on an LDS scene: the LDS copy holds pair records (k-th float4 of record r at s_nodes[k * 64 + r]) instead of nodes; the int
     // stack area then carries (node, tMin) entries for 8 levels, which the host guarantees to be enough
     if (LDS_SCENE && fast_walk) {
-        for (int i = threadIdx.x; i < 4 * sc.n_pairs; i += RT_BLOCK) s_nodes[(i & 3) * (RT_LDS_SCENE_NODES / 2) + (i >> 2)] = sc.pairs[i];
+        stage_pairs_lds(sc, s_nodes);
         for (int i = threadIdx.x; i < 3 * sc.n_slots; i += RT_BLOCK) s_slots[i] = sc.slots[i];
     } else if (LDS_SCENE) stage_scene_lds(sc, s_nodes, s_slots);
     PairStackT<8, false> pst; pst.lds_i = &s_stack[threadIdx.x]; pst.lds_t = (float *)&s_stack[8 * RT_BLOCK + threadIdx.x]; pst.reset();
@@ -823,7 +859,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, Sh
 // waits on global memory; results go out with plain stores; everything that needs a global read-modify-write or a
 // wave-wide append (emission, class binning, adding the unoccluded light) runs afterwards as a second, coalesced sweep
 // over the block's share.
-#define RT_FRAME_RING 8          // LDS ring entries per lane (node, tMin)
 enum { RT_WALK_QUADS = 1, RT_WALK_PAIRS = 2 };
 
 struct RayArrays { const float *ox, *oy, *oz, *dx, *dy, *dz; };
@@ -1265,9 +1300,10 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
         const rt_bvh_node &nd = sc->nodes[c];
         if (nd.nprim == 0) return (uint32_t)pairIndex[c];
         if (nd.nprim == 1) return RT_PAIR_LEAF | (uint32_t)nd.offset;
+        if (nd.nprim <= 128 && nd.offset < (1 << 22)) return RT_PAIR_LEAF_MULTI | RT_PAIR_LEAF_INLINE | ((uint32_t)(nd.nprim - 1) << 22) | (uint32_t)nd.offset;
         return RT_PAIR_LEAF_MULTI | (uint32_t)c;
     };
-    if (nn >= (1 << 30)) { set_error(ctx, "rt_scene_create: tree too large"); return -1; }
+    if (nn >= (1 << 29)) { set_error(ctx, "rt_scene_create: tree too large"); return -1; }
     std::vector<float> pairs(16 * (size_t)std::max(1, n_pairs), 0.f);
     for (int i = 0; i < nn; ++i) {
         if (sc->nodes[i].nprim != 0) continue;
@@ -1315,6 +1351,7 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
             const rt_bvh_node &nd = sc->nodes[c];
             if (nd.nprim == 0) return (uint32_t)quadIndex[c];
             if (nd.nprim == 1) return RT_PAIR_LEAF | (uint32_t)nd.offset;
+            if (nd.nprim <= 128 && nd.offset < (1 << 22)) return RT_PAIR_LEAF_MULTI | RT_PAIR_LEAF_INLINE | ((uint32_t)(nd.nprim - 1) << 22) | (uint32_t)nd.offset;
             return RT_PAIR_LEAF_MULTI | (uint32_t)c;
         };
         quads.assign(32 * (size_t)n_quads, 0.f);
@@ -1475,17 +1512,29 @@ static void bind_queue(PathQueue &q, void *base, size_t cap) {
 }
 
 extern "C++" {
+// Dynamic LDS of k_shade<.., LDS_TABLES = true>: the scene's shading tables.
+static size_t shade_lds_bytes(const DevScene &d) {
+    return (size_t)d.n_slots * (48 + 48 + 24 + 4) + (size_t)d.n_textures * sizeof(DevTexture) + (size_t)d.n_lights * sizeof(DevLight) +
+           (size_t)d.n_materials * sizeof(DevMaterial);
+}
+static bool shade_tables_in_lds(const DevScene &d) {
+    return d.n_slots <= RT_LDS_TAB_SLOTS && d.n_materials <= RT_LDS_TAB_MATERIALS && d.n_textures <= RT_LDS_TAB_TEXTURES && d.n_lights <= RT_LDS_TAB_LIGHTS &&
+           !env_int("RT_AMD_SHADE_GLOBAL_TABLES", 0);
+}
 template <int MAT>
 static void launch_shade(rt_scene *s, const RenderParams &rp, int bounce, const PathQueue &q, const PathQueue &qn, const HitBuf &hb, uint32_t cap,
-                         uint32_t segcap, const ShadowQueue &sq, int nseg) {
-    const bool lds_tables = s->dev.n_slots <= RT_LDS_TAB_SLOTS && s->dev.n_materials <= RT_LDS_TAB_MATERIALS && s->dev.n_textures <= RT_LDS_TAB_TEXTURES &&
-                            s->dev.n_lights <= RT_LDS_TAB_LIGHTS && !env_int("RT_AMD_SHADE_GLOBAL_TABLES", 0);
-    if (lds_tables)
-        hipLaunchKernelGGL((k_shade<MAT, true>), dim3(nseg), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p, cap,
-                           segcap, sq, (BounceCounts *)s->d_counters.p);
+                         uint32_t segcap, const ShadowQueue &sq, int nseg, bool fuse_shadow, float4 *lbuf, BounceStats *stats) {
+    const bool lds_tables = shade_tables_in_lds(s->dev);
+    const size_t dyn = lds_tables ? shade_lds_bytes(s->dev) : 0;
+    if (lds_tables && fuse_shadow)
+        hipLaunchKernelGGL((k_shade<MAT, true, true>), dim3(nseg), dim3(RT_BLOCK), dyn, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
+                           cap, segcap, sq, (BounceCounts *)s->d_counters.p, lbuf, stats);
+    else if (lds_tables)
+        hipLaunchKernelGGL((k_shade<MAT, true, false>), dim3(nseg), dim3(RT_BLOCK), dyn, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
+                           cap, segcap, sq, (BounceCounts *)s->d_counters.p, lbuf, stats);
     else
-        hipLaunchKernelGGL((k_shade<MAT, false>), dim3(nseg), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p, cap,
-                           segcap, sq, (BounceCounts *)s->d_counters.p);
+        hipLaunchKernelGGL((k_shade<MAT, false, false>), dim3(nseg), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
+                           cap, segcap, sq, (BounceCounts *)s->d_counters.p, lbuf, stats);
 }
 }  // extern "C++"
 
@@ -1568,6 +1617,8 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     const int round_bounces = env_int("RT_AMD_FRAME_ROUND_BOUNCES", small_tree ? 1 << 20 : 1);
     const int round_pairs = (this_->interior_depth <= 8 && env_int("RT_AMD_ROUND_PAIRS", 1)) ? 1 : 0;
     const int round_quads = (this_->dev.quads && env_int("RT_AMD_ROUND_PAIRS", 1)) ? 1 : 0;
+    // shadow rays traced inside the shading kernels: scenes whose tree and tables both sit in LDS
+    const bool fuse_shadow = lds_scene && round_pairs && !frame_old && shade_tables_in_lds(this_->dev) && env_int("RT_AMD_FUSE_SHADOW", 1) != 0;
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
         int cur = std::min(spb, o->sample_end - s0);
         rp.spb = cur; rp.sample0 = s0; rp.n_paths = (uint32_t)(npix * (size_t)cur);
@@ -1589,13 +1640,13 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                 hipLaunchKernelGGL(k_extend_pl<RT_WALK_PAIRS>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
                                    (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
             if (b < o->max_depth) {
-                if (this_->classes[RT_MAT_MATTE]) launch_shade<RT_MAT_MATTE>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg);
-                if (this_->classes[RT_MAT_MIRROR]) launch_shade<RT_MAT_MIRROR>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg);
-                if (this_->classes[RT_MAT_GLASS]) launch_shade<RT_MAT_GLASS>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg);
-                if (this_->classes[RT_MAT_METAL]) launch_shade<RT_MAT_METAL>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg);
-                if (this_->classes[RT_MAT_PLASTIC]) launch_shade<RT_MAT_PLASTIC>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg);
-                if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg);
-                if (this_->dev.n_lights > 0) {
+                if (this_->classes[RT_MAT_MATTE]) launch_shade<RT_MAT_MATTE>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
+                if (this_->classes[RT_MAT_MIRROR]) launch_shade<RT_MAT_MIRROR>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
+                if (this_->classes[RT_MAT_GLASS]) launch_shade<RT_MAT_GLASS>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
+                if (this_->classes[RT_MAT_METAL]) launch_shade<RT_MAT_METAL>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
+                if (this_->classes[RT_MAT_PLASTIC]) launch_shade<RT_MAT_PLASTIC>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
+                if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
+                if (this_->dev.n_lights > 0 && !fuse_shadow) {
                     if (frame_old || b < round_bounces) {
                         if (lds_scene)
                             hipLaunchKernelGGL(k_shadow<true>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
