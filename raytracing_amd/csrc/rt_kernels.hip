@@ -1066,6 +1066,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const float4 *lbuf, int
         sum_rgb[3 * (size_t)p] = r; sum_rgb[3 * (size_t)p + 1] = g; sum_rgb[3 * (size_t)p + 2] = b;
     }
 }
+// The same sum for passes with many samples per pixel: one wave per pixel reads the pixel's contiguous run of radiance slots
+// with coalesced loads (lane l takes samples l, l + 64, ...), then a fixed-order butterfly adds the 64 partial sums, so the
+// result does not depend on scheduling.
+__global__ __launch_bounds__(RT_BLOCK) void k_accumulate_wave(const float4 *lbuf, int spb, uint32_t npix, float *sum_rgb) {
+    const uint32_t lane = threadIdx.x & (RT_WAVE - 1), nwaves = gridDim.x * (RT_BLOCK / RT_WAVE);
+    for (uint32_t p = blockIdx.x * (RT_BLOCK / RT_WAVE) + threadIdx.x / RT_WAVE; p < npix; p += nwaves) {
+        const float4 *src = lbuf + (size_t)p * spb;
+        float r = 0.f, g = 0.f, b = 0.f;
+        for (int s = (int)lane; s < spb; s += RT_WAVE) { float4 L = src[s]; r += L.x; g += L.y; b += L.z; }
+#pragma unroll
+        for (int off = RT_WAVE / 2; off > 0; off >>= 1) { r += __shfl_down(r, off); g += __shfl_down(g, off); b += __shfl_down(b, off); }
+        if (lane == 0) { sum_rgb[3 * (size_t)p] += r; sum_rgb[3 * (size_t)p + 1] += g; sum_rgb[3 * (size_t)p + 2] += b; }
+    }
+}
 
 // ==================================================================== host ==
 struct rt_ctx {
@@ -1664,8 +1678,13 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
             }
             cq ^= 1;
         }
-        int ag = (int)std::min<size_t>((npix + RT_BLOCK - 1) / RT_BLOCK, (size_t)grid * 4);
-        hipLaunchKernelGGL(k_accumulate, dim3(ag), dim3(RT_BLOCK), 0, ctx->stream, (const float4 *)lbuf, cur, (uint32_t)npix, (float *)this_->d_sum.p);
+        if (cur >= 32) {
+            int ag = (int)std::min<size_t>((npix + RT_BLOCK / RT_WAVE - 1) / (RT_BLOCK / RT_WAVE), (size_t)grid * 8);
+            hipLaunchKernelGGL(k_accumulate_wave, dim3(ag), dim3(RT_BLOCK), 0, ctx->stream, (const float4 *)lbuf, cur, (uint32_t)npix, (float *)this_->d_sum.p);
+        } else {
+            int ag = (int)std::min<size_t>((npix + RT_BLOCK - 1) / RT_BLOCK, (size_t)grid * 4);
+            hipLaunchKernelGGL(k_accumulate, dim3(ag), dim3(RT_BLOCK), 0, ctx->stream, (const float4 *)lbuf, cur, (uint32_t)npix, (float *)this_->d_sum.p);
+        }
         HIP_OK(hipGetLastError());
         HIP_OK(hipMemcpyAsync(hs.data(), bstats, stats_bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIP_OK(hipStreamSynchronize(ctx->stream));
