@@ -25,8 +25,8 @@ $(LIBDIR)/librt_amd.so: $(CSRC)/rt_kernels.hip $(CSRC)/rt_device.h $(CSRC)/rt_ho
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/rt_kernels.hip -x hip $(CSRC)/rt_host_side.cpp
 
-$(LIBDIR)/librt_host.so: $(HOST)/rt_host.cpp $(HOST)/scenes.cpp $(HOST)/rt_host.h include/rt_amd.h $(LIBDIR)/librt_amd.so
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST)/rt_host.cpp $(HOST)/scenes.cpp -L$(LIBDIR) -lrt_amd -lz -Wl,-rpath,'$$ORIGIN'
+$(LIBDIR)/librt_host.so: $(HOST)/rt_host.cpp $(HOST)/scenes.cpp $(HOST)/jpeg_decode.cpp $(HOST)/rt_host.h include/rt_amd.h $(LIBDIR)/librt_amd.so
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST)/rt_host.cpp $(HOST)/scenes.cpp $(HOST)/jpeg_decode.cpp -L$(LIBDIR) -lrt_amd -lz -Wl,-rpath,'$$ORIGIN'
 
 clean:
 	rm -f $(LIBDIR)/*.so

@@ -44,17 +44,34 @@ def register_image_file(path, alias=None):
     host().rth_register_image((alias or os.path.basename(path)).encode(), im.shape[1], im.shape[0], capi.u8ptr(im))
 
 
+def decode_image(data):
+    """8-bit RGB pixels (H x W x 3) of a PNG or JPEG held in `data` (bytes), decoded by the host library's own readers."""
+    w = C.c_int(0); h = C.c_int(0)
+    if host().rth_decode_image(data, len(data), C.byref(w), C.byref(h), None) != 0:
+        raise ValueError("not a PNG / JPEG this library reads")
+    out = np.zeros((h.value, w.value, 3), np.uint8)
+    if host().rth_decode_image(data, len(data), C.byref(w), C.byref(h), capi.u8ptr(out)) != 0:
+        raise ValueError("decode failed")
+    return out
+
+
+def model_probe(path, apply_node_transforms=False):
+    """Triangles (n, 3, 3), uvs (n, 3, 2) and the (base colour, metal-roughness) texture names ModelLoad takes from a .gltf / .glb."""
+    n = C.c_int(0)
+    if host().rth_model_probe(path.encode(), int(apply_node_transforms), C.byref(n), None, None, None, 0) != 0:
+        raise RuntimeError("cannot load " + path)
+    p = np.zeros((n.value, 3, 3), np.float32); uv = np.zeros((n.value, 3, 2), np.float32)
+    names = C.create_string_buffer(1024)
+    host().rth_model_probe(path.encode(), int(apply_node_transforms), C.byref(n), capi.fptr(p), capi.fptr(uv), names, 1024)
+    return p, uv, tuple(names.value.decode().split("|"))
+
+
 class HostScene:
     """A scene built by the C++ host surface (raytracing_amd/host/scenes.cpp) and flattened to an rt_scene_desc."""
 
     def __init__(self, name, param=0, assets_dir=None):
         assets_dir = assets_dir or default_assets_dir()
-        if name == "spheres2":
-            register_image_file(os.path.join(assets_dir, "earthmap.jpg"))
-        if name == "helmet":
-            # DamagedHelmet.gltf names PNG files; the reference tree only holds their JPEG twins.
-            for f in ("Default_albedo", "Default_metalRoughness"):
-                register_image_file(os.path.join(assets_dir, "DamagedHelmet", "glTF", f + ".jpg"), alias=f + ".png")
+        # textures (earthmap.jpg, the helmet's JPEG twins of the PNG names in its .gltf) are decoded by the host library itself
         self.name = name
         self._h = host().rth_scene_build(name.encode(), assets_dir.encode(), int(param))
         if not self._h:

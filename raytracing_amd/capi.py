@@ -124,6 +124,8 @@ def load_rt_host():
     lib.rth_scene_camera.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Camera)]
     lib.rth_scene_free.argtypes = [vp]; lib.rth_scene_free.restype = None
     lib.rth_register_image.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint8)]; lib.rth_register_image.restype = None
+    lib.rth_decode_image.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint8)]
+    lib.rth_model_probe.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_char_p, C.c_int]
     lib.rth_render_like_main.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
                                          C.POINTER(C.c_float), C.POINTER(RenderStats)]
     lib.rth_kat_transform.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float),

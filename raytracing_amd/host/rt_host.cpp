@@ -166,10 +166,7 @@ uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1
 int paeth(int a, int b, int c) { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
 
 // Non-interlaced PNG, 8 or 16 bits per channel, all colour types -> 8-bit RGB.
-bool DecodePNG(const std::string &path, Raw8 *out) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) return false;
-    std::vector<uint8_t> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+bool DecodePNG(const std::vector<uint8_t> &buf, Raw8 *out) {
     static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
     if (buf.size() < 8 || memcmp(buf.data(), sig, 8) != 0) return false;
     size_t pos = 8; uint32_t w = 0, h = 0; int depth = 0, ctype = 0, interlace = 0;
@@ -237,6 +234,17 @@ int RoundUpPow2(int v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8
 bool IsPow2(int v) { return v && !(v & (v - 1)); }
 }  // namespace
 
+bool DecodeImageRGB8(const uint8_t *data, size_t size, int *width, int *height, std::vector<uint8_t> *rgb) {
+    if (size >= 8 && data[0] == 137 && data[1] == 'P') {
+        Raw8 r; std::vector<uint8_t> buf(data, data + size);
+        if (!DecodePNG(buf, &r)) return false;
+        *width = r.w; *height = r.h; *rgb = std::move(r.rgb);
+        return true;
+    }
+    if (size >= 3 && data[0] == 0xFF && data[1] == 0xD8) return DecodeJPEG(data, size, width, height, rgb);
+    return false;
+}
+
 void RegisterImage(const std::string &name, int width, int height, const uint8_t *rgb8) {
     Raw8 r; r.w = width; r.h = height; r.rgb.assign(rgb8, rgb8 + (size_t)width * height * 3);
     Registry()[BaseName(NormalizePath(name))] = std::move(r);
@@ -247,7 +255,18 @@ std::shared_ptr<ImageData> LoadImageRGB(const std::string &filename) {
     Raw8 raw; const Raw8 *src = nullptr;
     auto it = Registry().find(BaseName(path));
     if (it != Registry().end()) src = &it->second;
-    else if (DecodePNG(path, &raw)) src = &raw;
+    else {
+        // The file itself; failing that its JPEG twin (DamagedHelmet.gltf names Default_albedo.png, the model ships Default_albedo.jpg).
+        std::vector<std::string> tries = {path};
+        size_t dot = path.find_last_of('.');
+        if (dot != std::string::npos && path.substr(dot) == ".png") { tries.push_back(path.substr(0, dot) + ".jpg"); tries.push_back(path.substr(0, dot) + ".jpeg"); }
+        for (const std::string &t : tries) {
+            std::ifstream f(t, std::ios::binary);
+            if (!f) continue;
+            std::vector<uint8_t> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+            if (DecodeImageRGB8(buf.data(), buf.size(), &raw.w, &raw.h, &raw.rgb)) { src = &raw; break; }
+        }
+    }
     if (!src) return nullptr;
     auto img = std::make_shared<ImageData>();
     img->width = src->w; img->height = src->h; img->rgb.resize(src->rgb.size());
@@ -528,17 +547,78 @@ std::vector<uint8_t> ReadFileBytes(const std::string &path) {
 }
 }  // namespace
 
+namespace {
+std::vector<uint8_t> Base64(const std::string &t, size_t from) {
+    std::vector<uint8_t> out; uint32_t acc = 0; int bits = 0;
+    for (size_t i = from; i < t.size(); ++i) {
+        char c = t[i]; int v;
+        if (c >= 'A' && c <= 'Z') v = c - 'A'; else if (c >= 'a' && c <= 'z') v = c - 'a' + 26; else if (c >= '0' && c <= '9') v = c - '0' + 52;
+        else if (c == '+' || c == '-') v = 62; else if (c == '/' || c == '_') v = 63; else continue;
+        acc = (acc << 6) | (uint32_t)v; bits += 6;
+        if (bits >= 8) { bits -= 8; out.push_back((uint8_t)(acc >> bits)); }
+    }
+    return out;
+}
+uint32_t le32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+// Column-major 4x4 (glTF) helpers for node transforms, in double.
+struct M4 { double m[16]; };
+M4 M4Identity() { M4 r; for (int i = 0; i < 16; ++i) r.m[i] = (i % 5 == 0) ? 1.0 : 0.0; return r; }
+M4 M4Mul(const M4 &a, const M4 &b) {
+    M4 r;
+    for (int c = 0; c < 4; ++c) for (int rr = 0; rr < 4; ++rr) { double v = 0; for (int k = 0; k < 4; ++k) v += a.m[k * 4 + rr] * b.m[c * 4 + k]; r.m[c * 4 + rr] = v; }
+    return r;
+}
+M4 NodeLocal(const JVal &nd) {       // glTF 2.0: `matrix`, or translation * rotation * scale
+    M4 r = M4Identity();
+    if (const JVal *mx = nd.get("matrix")) { if (mx->a.size() == 16) for (int i = 0; i < 16; ++i) r.m[i] = mx->a[i].num; return r; }
+    double t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, sc[3] = {1, 1, 1};
+    if (const JVal *v = nd.get("translation")) if (v->a.size() == 3) for (int i = 0; i < 3; ++i) t[i] = v->a[i].num;
+    if (const JVal *v = nd.get("rotation")) if (v->a.size() == 4) for (int i = 0; i < 4; ++i) q[i] = v->a[i].num;
+    if (const JVal *v = nd.get("scale")) if (v->a.size() == 3) for (int i = 0; i < 3; ++i) sc[i] = v->a[i].num;
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w),      // column 0
+                   2 * (x * y - z * w), 1 - 2 * (x * x + z * z), 2 * (y * z + x * w),      // column 1
+                   2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y)};     // column 2
+    for (int c = 0; c < 3; ++c) for (int rr = 0; rr < 3; ++rr) r.m[c * 4 + rr] = R[c * 3 + rr] * sc[c];
+    r.m[12] = t[0]; r.m[13] = t[1]; r.m[14] = t[2];
+    return r;
+}
+}  // namespace
+
+// Reads .gltf (external or base64 buffers and images) and .glb (binary container, images in buffer views).  What is taken from
+// the file and how follows the reference's Assimp-based loader (modelload.cpp:7-125, import flags :8-9): positions and normals
+// with z negated, v flipped, the node hierarchy walked meshes-first — and, like it, node transforms are NOT applied unless
+// applyNodeTransforms is set (an extension: the node's matrix / TRS chain is then applied to the raw positions before the z flip).
 void ModelLoad::loadModel(string path, const Transform &ObjectToWorld) {
     path = NormalizePath(path);
     std::vector<uint8_t> text = ReadFileBytes(path);
     if (text.empty()) { std::cout << "ERROR::GLTF::cannot read " << path << std::endl; return; }
     size_t slash = path.find_last_of('/');
     directory = slash == std::string::npos ? "." : path.substr(0, slash);
-    std::string js(text.begin(), text.end());
+    const std::string fileName = BaseName(path);
+    std::vector<uint8_t> glbBin; bool isGlb = false;
+    std::string js;
+    if (text.size() >= 20 && le32(text.data()) == 0x46546C67u) {         // "glTF": 12-byte header, then chunks (length, type, data)
+        isGlb = true;
+        size_t pos = 12, total = std::min<size_t>(text.size(), le32(text.data() + 8));
+        while (pos + 8 <= total) {
+            uint32_t len = le32(&text[pos]), type = le32(&text[pos + 4]);
+            if (pos + 8 + (size_t)len > total) break;
+            if (type == 0x4E4F534Au && js.empty()) js.assign(text.begin() + pos + 8, text.begin() + pos + 8 + len);
+            else if (type == 0x004E4942u && glbBin.empty()) glbBin.assign(text.begin() + pos + 8, text.begin() + pos + 8 + len);
+            pos += 8 + (((size_t)len + 3) & ~(size_t)3);
+        }
+        if (js.empty()) { std::cout << "ERROR::GLB::no JSON chunk in " << path << std::endl; return; }
+    } else js.assign(text.begin(), text.end());
     JVal root;
     try { root = JParser(js).parse(); } catch (std::exception &e) { std::cout << "ERROR::GLTF::" << e.what() << std::endl; return; }
     std::vector<std::vector<uint8_t>> buffers;
-    if (const JVal *bs = root.get("buffers")) for (const JVal &b : bs->a) { const JVal *uri = b.get("uri"); buffers.push_back(uri ? ReadFileBytes(directory + "/" + uri->s) : std::vector<uint8_t>()); }
+    if (const JVal *bs = root.get("buffers")) for (const JVal &b : bs->a) {
+        const JVal *uri = b.get("uri");
+        if (!uri) buffers.push_back(isGlb && buffers.empty() ? glbBin : std::vector<uint8_t>());
+        else if (uri->s.compare(0, 5, "data:") == 0) { size_t c = uri->s.find(','); buffers.push_back(c == std::string::npos ? std::vector<uint8_t>() : Base64(uri->s, c + 1)); }
+        else buffers.push_back(ReadFileBytes(directory + "/" + uri->s));
+    }
     const JVal *views = root.get("bufferViews"), *accs = root.get("accessors"), *jmeshes = root.get("meshes");
     if (!views || !accs || !jmeshes) { std::cout << "ERROR::GLTF::incomplete scene" << std::endl; return; }
     auto accessor = [&](int idx, int *count, int *ctype, int *ncomp, int *stride) -> const uint8_t * {
@@ -561,9 +641,34 @@ void ModelLoad::loadModel(string path, const Transform &ObjectToWorld) {
         const JVal *texs = root.get("textures"), *imgs = root.get("images"); if (!texs || !imgs) return "";
         int ti = t->geti("index"); if (ti < 0 || ti >= (int)texs->a.size()) return "";
         int src = texs->a[ti].geti("source"); if (src < 0 || src >= (int)imgs->a.size()) return "";
-        const JVal *uri = imgs->a[src].get("uri"); return uri ? uri->s : "";
+        const JVal &im = imgs->a[src];
+        const JVal *uri = im.get("uri");
+        if (uri && uri->s.compare(0, 5, "data:") != 0) return uri->s;
+        // embedded image (buffer view or data URI): decode now and make it known under a name of its own
+        std::string name = fileName + "#image" + std::to_string(src);
+        std::vector<uint8_t> bytes;
+        if (uri) { size_t c = uri->s.find(','); if (c != std::string::npos) bytes = Base64(uri->s, c + 1); }
+        else {
+            int vi = im.geti("bufferView");
+            if (vi >= 0 && vi < (int)views->a.size()) {
+                const JVal &v = views->a[vi]; int bi = v.geti("buffer", 0);
+                size_t off = (size_t)v.geti("byteOffset", 0), len = (size_t)v.geti("byteLength", 0);
+                if (bi >= 0 && bi < (int)buffers.size() && off + len <= buffers[bi].size()) bytes.assign(buffers[bi].begin() + off, buffers[bi].begin() + off + len);
+            }
+        }
+        int w = 0, h = 0; std::vector<uint8_t> rgb;
+        if (bytes.empty() || !DecodeImageRGB8(bytes.data(), bytes.size(), &w, &h, &rgb)) return "";
+        RegisterImage(name, w, h, rgb.data());
+        return name;
     };
-    auto addMesh = [&](const JVal &mesh) {
+    auto addMesh = [&](const JVal &mesh, const M4 &world) {
+        const bool xf = applyNodeTransforms;
+        // normals go through the cofactor matrix of the upper 3x3 (= inverse transpose up to a positive or negative scale)
+        const double *a = world.m;
+        const double cof[9] = {a[5] * a[10] - a[6] * a[9], a[6] * a[8] - a[4] * a[10], a[4] * a[9] - a[5] * a[8],
+                               a[2] * a[9] - a[1] * a[10], a[0] * a[10] - a[2] * a[8], a[1] * a[8] - a[0] * a[9],
+                               a[1] * a[6] - a[2] * a[5], a[2] * a[4] - a[0] * a[6], a[0] * a[5] - a[1] * a[4]};
+        const double det = a[0] * cof[0] + a[1] * cof[1] + a[2] * cof[2];
         const JVal *prims = mesh.get("primitives"); if (!prims) return;
         for (const JVal &pr : prims->a) {
             const JVal *attr = pr.get("attributes"); if (!attr) continue;
@@ -572,9 +677,25 @@ void ModelLoad::loadModel(string path, const Transform &ObjectToWorld) {
             if (!pos || ct != 5126 || nc != 3) continue;
             int nVerts = n, pst = st;
             std::vector<Point3f> P(nVerts); std::vector<Normal3f> N; std::vector<Point2f> UV;
-            for (int i = 0; i < nVerts; ++i) { float v[3]; memcpy(v, pos + (size_t)i * pst, 12); P[i] = Point3f(v[0], v[1], -v[2]); }
+            for (int i = 0; i < nVerts; ++i) {
+                float v[3]; memcpy(v, pos + (size_t)i * pst, 12);
+                if (xf) { double x = v[0], y = v[1], z = v[2]; v[0] = (float)(a[0] * x + a[4] * y + a[8] * z + a[12]); v[1] = (float)(a[1] * x + a[5] * y + a[9] * z + a[13]); v[2] = (float)(a[2] * x + a[6] * y + a[10] * z + a[14]); }
+                P[i] = Point3f(v[0], v[1], -v[2]);
+            }
             const uint8_t *nor = accessor(attr->geti("NORMAL"), &n, &ct, &nc, &st);
-            if (nor && ct == 5126 && nc == 3 && n == nVerts) { N.resize(nVerts); for (int i = 0; i < nVerts; ++i) { float v[3]; memcpy(v, nor + (size_t)i * st, 12); N[i] = Normal3f(v[0], v[1], -v[2]); } }
+            if (nor && ct == 5126 && nc == 3 && n == nVerts) {
+                N.resize(nVerts);
+                for (int i = 0; i < nVerts; ++i) {
+                    float v[3]; memcpy(v, nor + (size_t)i * st, 12);
+                    if (xf) {
+                        double x = v[0], y = v[1], z = v[2], sgn = det < 0 ? -1.0 : 1.0;
+                        double nx = sgn * (cof[0] * x + cof[3] * y + cof[6] * z), ny = sgn * (cof[1] * x + cof[4] * y + cof[7] * z), nz = sgn * (cof[2] * x + cof[5] * y + cof[8] * z);
+                        double len = std::sqrt(nx * nx + ny * ny + nz * nz);
+                        if (len > 0) { v[0] = (float)(nx / len); v[1] = (float)(ny / len); v[2] = (float)(nz / len); }
+                    }
+                    N[i] = Normal3f(v[0], v[1], -v[2]);
+                }
+            }
             const uint8_t *tc = accessor(attr->geti("TEXCOORD_0"), &n, &ct, &nc, &st);
             if (tc && ct == 5126 && nc == 2 && n == nVerts) { UV.resize(nVerts); for (int i = 0; i < nVerts; ++i) { float v[2]; memcpy(v, tc + (size_t)i * st, 8); UV[i] = Point2f(v[0], 1 - v[1]); } }
             std::vector<int> idx;
@@ -602,14 +723,15 @@ void ModelLoad::loadModel(string path, const Transform &ObjectToWorld) {
     std::vector<int> stack;
     if (nodes && scenes && !scenes->a.empty()) {
         const JVal &sc = scenes->a[std::max(0, root.geti("scene", 0))];
-        std::function<void(int)> walk = [&](int ni) {
-            if (ni < 0 || ni >= (int)nodes->a.size()) return;
+        std::function<void(int, const M4 &, int)> walk = [&](int ni, const M4 &parent, int depth) {
+            if (ni < 0 || ni >= (int)nodes->a.size() || depth > 64) return;
             const JVal &nd = nodes->a[ni];
-            int mi = nd.geti("mesh"); if (mi >= 0 && mi < (int)jmeshes->a.size()) addMesh(jmeshes->a[mi]);
-            if (const JVal *ch = nd.get("children")) for (const JVal &c : ch->a) walk((int)c.num);
+            M4 world = M4Mul(parent, NodeLocal(nd));
+            int mi = nd.geti("mesh"); if (mi >= 0 && mi < (int)jmeshes->a.size()) addMesh(jmeshes->a[mi], world);
+            if (const JVal *ch = nd.get("children")) for (const JVal &c : ch->a) walk((int)c.num, world, depth + 1);
         };
-        if (const JVal *rn = sc.get("nodes")) for (const JVal &r : rn->a) walk((int)r.num);
-    } else for (const JVal &m : jmeshes->a) addMesh(m);
+        if (const JVal *rn = sc.get("nodes")) for (const JVal &r : rn->a) walk((int)r.num, M4Identity(), 0);
+    } else for (const JVal &m : jmeshes->a) addMesh(m, M4Identity());
 }
 
 void ModelLoad::buildNoTextureModel(Transform &o2w, vector<shared_ptr<Primitive>> &prims, shared_ptr<Material> material) {

@@ -240,7 +240,11 @@ public:
 // Decoded image: float RGB, row-major, after the reference's load conventions
 // (8-bit / 255, no gamma: imageio.cpp:19-45; Lanczos resample to powers of two: mipmap.h:70-121).
 struct ImageData { int width = 0, height = 0; std::vector<float> rgb; };
-// Read an image file (PNG natively; anything registered with RegisterImage by name first).
+// 8-bit RGB pixels of a PNG (non-interlaced) or JPEG (baseline / progressive Huffman) held in memory.
+bool DecodeImageRGB8(const uint8_t *data, size_t size, int *width, int *height, std::vector<uint8_t> *rgb);
+bool DecodeJPEG(const uint8_t *data, size_t size, int *width, int *height, std::vector<uint8_t> *rgb);   // jpeg_decode.cpp
+// Read an image file (PNG and JPEG natively; a ".png" that is missing falls back to its ".jpg" twin; images registered
+// with RegisterImage by name come first).
 // Returns nullptr when the file cannot be decoded.
 std::shared_ptr<ImageData> LoadImageRGB(const std::string &filename);
 // Make 8-bit RGB pixels available under `name` (used for formats this library does not decode itself).
@@ -523,6 +527,7 @@ public:
     vector<shared_ptr<TriangleMesh>> meshes;
     string directory;
     vector<string> specTexName, diffTexName;
+    bool applyNodeTransforms = false;   // extension (the reference never reads a node's transform, modelload.cpp:18-25)
     void loadModel(string path, const Transform &ObjectToWorld);
     void buildNoTextureModel(Transform &tri_Object2World, vector<shared_ptr<Primitive>> &prims, shared_ptr<Material> material);
     void buildTextureModel(Transform &tri_Object2World, vector<shared_ptr<Primitive>> &prims);

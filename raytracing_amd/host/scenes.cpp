@@ -141,7 +141,7 @@ void BuildSpheres(BuiltScene &bs, bool extended, const std::string &assets) {
     bs.lookat = LookAt(Point3f(13, 2, 3), Point3f(0.f, 0.f, 0.f), Vector3f(0.0f, 1.0f, 0.0f));
 }
 
-void BuildHelmet(BuiltScene &bs, const std::string &assets) {
+void BuildHelmet(BuiltScene &bs, const std::string &assets, const std::string &model = "/DamagedHelmet/glTF/DamagedHelmet.gltf") {
     std::vector<std::shared_ptr<Primitive>> prims; std::vector<std::shared_ptr<Light>> lights;
     std::shared_ptr<Material> m1 = Matte(Spectrum(1.0f, 1.0f, 1.0f));
     AddCeilingLight(bs, prims, lights, m1, 25.f);
@@ -152,8 +152,8 @@ void BuildHelmet(BuiltScene &bs, const std::string &assets) {
     Transform o2w = Translate(Vector3f(ts, ts, ts)) * RotateY(-90) * RotateX(-90);
     bs.loaders.emplace_back(new ModelLoad);
     ModelLoad &ML = *bs.loaders.back();
-    ML.loadModel(assets + "/DamagedHelmet/glTF/DamagedHelmet.gltf", o2w);
-    if (ML.meshes.empty()) throw std::runtime_error("helmet: could not load " + assets + "/DamagedHelmet/glTF/DamagedHelmet.gltf");
+    ML.loadModel(assets + model, o2w);
+    if (ML.meshes.empty()) throw std::runtime_error("helmet: could not load " + assets + model);
     ML.buildTextureModel(o2w, prims);
     bs.scene = make_shared<Scene>(make_shared<BVHAccel>(prims), lights);
     bs.lookat = LookAt(Point3f(1.f + ts, 0.7f + ts, -1.f + ts), Point3f(-0.5f + ts, -0.2f + ts, 0.3f + ts), Vector3f(0.0f, 1.0f, 0.0f));
@@ -210,6 +210,7 @@ rth_scene *rth_scene_build(const char *name, const char *assets_dir, int64_t par
         else if (nm == "sphere1") BuildSpheres(h->b, false, assets);
         else if (nm == "spheres2") BuildSpheres(h->b, true, assets);
         else if (nm == "helmet") BuildHelmet(h->b, assets);
+        else if (nm == "helmet_glb") BuildHelmet(h->b, assets, "/DamagedHelmet/glTF-Binary/DamagedHelmet.glb");   // the same model as one binary container
         else if (nm == "soup") BuildSoup(h->b, param);
         else throw std::runtime_error("unknown scene '" + nm + "'");
         if (!h->b.flat) h->b.flat = FlattenScene(*h->b.scene);
@@ -224,6 +225,39 @@ int rth_scene_camera(rth_scene *h, int width, int height, rt_camera *out) {
 }
 void rth_scene_free(rth_scene *h) { delete h; }
 void rth_register_image(const char *name, int w, int h, const uint8_t *rgb8) { RegisterImage(name, w, h, rgb8); }
+// Load a .gltf / .glb with ModelLoad and hand back its triangles as the loader leaves them (object space of ObjectToWorld =
+// identity): 9 floats of positions and 6 of uv per triangle, and the texture names of the first mesh.  Pass null outputs to
+// learn n_tris first.  0 = ok.
+int rth_model_probe(const char *path, int apply_node_transforms, int *n_tris, float *tri_p, float *tri_uv, char *names, int names_cap) {
+    if (!path || !n_tris) return -1;
+    ModelLoad ML; ML.applyNodeTransforms = apply_node_transforms != 0;
+    Transform id;
+    ML.loadModel(path, id);
+    if (ML.meshes.empty()) return -1;
+    int n = 0;
+    for (auto &m : ML.meshes) {
+        for (int t = 0; t < m->nTriangles; ++t, ++n) {
+            if (!tri_p) continue;
+            for (int k = 0; k < 3; ++k) {
+                int v = m->vertexIndices[3 * t + k];
+                tri_p[9 * n + 3 * k] = m->p[v].x; tri_p[9 * n + 3 * k + 1] = m->p[v].y; tri_p[9 * n + 3 * k + 2] = m->p[v].z;
+                if (tri_uv) { tri_uv[6 * n + 2 * k] = m->uv ? m->uv[v].x : 0.f; tri_uv[6 * n + 2 * k + 1] = m->uv ? m->uv[v].y : 0.f; }
+            }
+        }
+    }
+    *n_tris = n;
+    if (names && names_cap > 0) snprintf(names, (size_t)names_cap, "%s|%s", ML.diffTexName.empty() ? "" : ML.diffTexName[0].c_str(), ML.specTexName.empty() ? "" : ML.specTexName[0].c_str());
+    return 0;
+}
+// Decode a PNG / JPEG held in memory.  Call with out == nullptr for the size, then with a w*h*3 buffer.  0 = ok.
+int rth_decode_image(const uint8_t *data, size_t size, int *w, int *h, uint8_t *out) {
+    static thread_local std::vector<uint8_t> last; static thread_local const uint8_t *last_data = nullptr; static thread_local int lw = 0, lh = 0;
+    if (!data || !w || !h) return -1;
+    if (last_data != data || last.empty()) { if (!DecodeImageRGB8(data, size, &lw, &lh, &last)) { last.clear(); last_data = nullptr; return -1; } last_data = data; }
+    *w = lw; *h = lh;
+    if (out) { memcpy(out, last.data(), last.size()); last.clear(); last_data = nullptr; }
+    return 0;
+}
 
 // Render a named scene the way the reference's main() does (RayTracing.cpp:410-434): through
 // PathIntegrator::Render, i.e. the drop-in path.  out_sum: w*h*3 floats.
