@@ -390,6 +390,118 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, RenderParams r
     if (threadIdx.x < RT_NUM_CLASSES) bc->cls[threadIdx.x][blockIdx.x] = s_cls[threadIdx.x];
 }
 
+// k_extend for scenes that live in LDS, with carry-over: a lane whose ray is finished after RT_CARRY_ROUNDS rounds of
+// (interior steps until every walking lane holds a leaf, then the leaf tests) hands in its result and takes the next ray of
+// its wave's range, while lanes with long rays keep theirs.  A wave therefore no longer waits for its slowest ray after every
+// 64 rays, and the hand-in / take-over code still runs for most of the wave at once.
+#ifndef RT_CARRY_ROUNDS
+#define RT_CARRY_ROUNDS 2
+#endif
+__global__ __launch_bounds__(RT_BLOCK) void k_extend_carry(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
+                                                            uint32_t segcap, float4 *lbuf, BounceCounts *counts, BounceStats *stats) {
+    __shared__ int s_stack[2 * RT_FRAME_RING * RT_BLOCK];
+    __shared__ float4 s_nodes[2 * RT_LDS_SCENE_NODES], s_slots[3 * RT_LDS_SCENE_SLOTS];
+    stage_pairs_lds(sc, s_nodes);
+    for (int i = threadIdx.x; i < 3 * sc.n_slots; i += RT_BLOCK) s_slots[i] = sc.slots[i];
+    PairStackT<RT_FRAME_RING, false> pst; pst.lds_i = &s_stack[threadIdx.x]; pst.lds_t = (float *)&s_stack[RT_FRAME_RING * RT_BLOCK + threadIdx.x]; pst.reset();
+    __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE], s_cls[RT_NUM_CLASSES];
+    BounceCounts *bc = counts + bounce;
+    if (threadIdx.x < RT_NUM_CLASSES) s_cls[threadIdx.x] = 0;
+    const uint32_t total = segment_prefix(bc->queue, s_prefix, s_wave);
+    uint32_t lo, hi;
+    block_share(total, lo, hi);
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_queue = total;
+    if (threadIdx.x == 0) { bc->shadow[blockIdx.x] = 0; counts[bounce + 1].queue[blockIdx.x] = 0; }
+    const uint32_t wave = threadIdx.x / RT_WAVE;
+    const uint32_t per = (((hi - lo) + RT_BLOCK / RT_WAVE - 1) / (RT_BLOCK / RT_WAVE) + RT_WAVE - 1) & ~(uint32_t)(RT_WAVE - 1);
+    const uint32_t w_lo = lo + wave * per < hi ? lo + wave * per : hi, w_hi = w_lo + per < hi ? w_lo + per : hi;
+    uint32_t w_next = w_lo;
+    uint32_t seg = w_lo < w_hi ? segment_of(s_prefix, w_lo) : 0;      // per-lane cursor; a lane's positions only grow
+    const uint32_t seg_base = blockIdx.x * segcap;
+    LaneTrav L = {};
+    L.mode = RT_LANE_DONE; L.hitSlot = -1;
+    bool busy = false;
+    uint32_t cur_i = 0, dummy = 0;
+    while (true) {
+        // ---- hand in finished rays: hit record, emission / sky / termination (integrator.cpp:242-257), class binning
+        const bool fin = busy && L.mode == RT_LANE_DONE;
+        int cls = -1;
+        if (fin) {
+            const uint32_t i = cur_i;
+            const bool found = L.found;
+            const int slot = found ? L.hitSlot : -1;
+            hb.slot[i] = slot; hb.t[i] = L.tmax; hb.b0[i] = L.b0; hb.b1[i] = L.b1; hb.b2[i] = L.b2;
+            const uint32_t state = q.state[i];
+            const int depth = state & 0xFFFF; const bool spec = (state >> 16) & 1;
+            F3 add = f3(0.f, 0.f, 0.f); bool terminal = false;
+            if (depth == 0 || spec || sc.n_lights == 0) {
+                if (found) {
+                    int li = sc.slot_light[slot];
+                    if (li >= 0) {
+                        const DevLight &Lt = sc.lights[li];
+                        float4 nf = sc.frames[3 * slot];
+                        if (Lt.two_sided || dot3(f3(nf.x, nf.y, nf.z), -L.d) > 0) add = f3(Lt.Le[0], Lt.Le[1], Lt.Le[2]);   // light.h:73-75
+                        if (!black3(add)) terminal = true;
+                    }
+                } else if (sc.n_lights == 0) {
+                    F3 ud = normalize3(L.d);
+                    double t = 0.5 * (ud.y + 1.0);
+                    float a = (float)(1.0 - t), b = (float)t;
+                    add = f3(1.0f * a + 0.5f * b, 1.0f * a + 0.7f * b, 1.0f * a + 1.0f * b);
+                }
+            }
+            if (!found || depth >= rp.max_depth) terminal = true;
+            if (!black3(add)) {
+                uint32_t id = q.id[i];
+                float4 Lr = lbuf[id];
+                Lr.x += q.tr[i] * add.x; Lr.y += q.tg[i] * add.y; Lr.z += q.tb[i] * add.z;
+                lbuf[id] = Lr;
+            }
+            if (!terminal) cls = sc.materials[sc.slot_material[slot]].kind;
+            busy = false;
+        }
+        if (__ballot(fin) != 0)
+            for (int c = 0; c < RT_NUM_CLASSES; ++c) {
+                bool mine = (cls == c);
+                if (__ballot(mine) == 0) continue;
+                uint32_t pos = block_append(mine, &s_cls[c]);
+                if (mine) cls_list[(size_t)c * cap + seg_base + pos] = cur_i;
+            }
+        // ---- take the next rays of the wave's range
+        const uint64_t im = __ballot(!busy);
+        const uint32_t left = w_hi - w_next, nidle = (uint32_t)__popcll(im), take = nidle < left ? nidle : left;
+        if (!busy && prefix_in_mask(im) < take) {
+            uint32_t g = w_next + prefix_in_mask(im);
+            while (g >= s_prefix[seg + 1]) seg++;
+            cur_i = seg * segcap + (g - s_prefix[seg]);
+            F3 o = f3(q.ox[cur_i], q.oy[cur_i], q.oz[cur_i]), d = f3(q.dx[cur_i], q.dy[cur_i], q.dz[cur_i]);
+            bool have = lane_begin<false>(sc, L, pst, o, d, RT_INF, dummy);
+            lane_enter(sc, L, sc.root_info, have);
+            busy = true;
+        }
+        w_next += take;
+        if (__ballot(busy) == 0) break;
+        // ---- a few rounds of traversal for every lane that holds a ray
+#pragma unroll 1
+        for (int k = 0; k < RT_CARRY_ROUNDS; ++k) {
+            while (L.mode == RT_LANE_WALK) {
+                uint32_t info; bool hv;
+                if (L.plain) lane_walk<false, true, RT_LDS_SCENE_NODES / 2>(s_nodes, L, pst, dummy, info, hv);
+                else lane_walk<false, false, RT_LDS_SCENE_NODES / 2>(s_nodes, L, pst, dummy, info, hv);
+                lane_enter(sc, L, info, hv);
+            }
+            if (L.mode == RT_LANE_LEAF) {
+                LeafOut r = lane_leaf<false, false>(sc, s_slots, L, pst, dummy);
+                L.found = r.found; L.tmax = r.tmax; L.hitSlot = r.hitSlot; L.b0 = r.b0; L.b1 = r.b1; L.b2 = r.b2;
+                lane_enter(sc, L, r.info, r.have);
+            }
+            if (__ballot(L.mode != RT_LANE_DONE) == 0) break;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < RT_NUM_CLASSES) bc->cls[threadIdx.x][blockIdx.x] = s_cls[threadIdx.x];
+}
+
 // ------------------------------------------------------------------- shade --
 struct SurfacePoint { F3 p, n, ss, ts, wo; float u, v; };
 
@@ -1631,6 +1743,8 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     const int round_bounces = env_int("RT_AMD_FRAME_ROUND_BOUNCES", small_tree ? 1 << 20 : 1);
     const int round_pairs = (this_->interior_depth <= 8 && env_int("RT_AMD_ROUND_PAIRS", 1)) ? 1 : 0;
     const int round_quads = (this_->dev.quads && env_int("RT_AMD_ROUND_PAIRS", 1)) ? 1 : 0;
+    // incoherent bounces of LDS scenes: lanes carry long rays over and refill (k_extend_carry); camera rays stay round-based
+    const int carry_from = env_int("RT_AMD_CARRY_FROM", 1);
     // shadow rays traced inside the shading kernels: scenes whose tree and tables both sit in LDS
     const bool fuse_shadow = lds_scene && round_pairs && !frame_old && shade_tables_in_lds(this_->dev) && env_int("RT_AMD_FUSE_SHADOW", 1) != 0;
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
@@ -1641,7 +1755,10 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
         int cq = 0;
         for (int b = 0; b <= o->max_depth; ++b) {
             if (frame_old || b < round_bounces) {
-                if (lds_scene)
+                if (lds_scene && round_pairs && b >= carry_from)
+                    hipLaunchKernelGGL(k_extend_carry, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
+                                       ucap, useg, lbuf, counts, bstats);
+                else if (lds_scene)
                     hipLaunchKernelGGL(k_extend<true>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
                                        ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, round_pairs);
                 else
