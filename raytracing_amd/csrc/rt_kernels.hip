@@ -68,6 +68,7 @@ struct RenderParams {
     int max_depth;
     uint32_t k0, k1;
     uint32_t n_paths;
+    int rr_shade;       // shading kernels take their chunks round robin (block_chunks)
 };
 
 // ---------------------------------------------------------------- helpers --
@@ -96,7 +97,20 @@ __device__ __forceinline__ uint32_t segment_prefix(const uint32_t *__restrict__ 
     __syncthreads();
     return s_prefix[gridDim.x];
 }
-// This block's share [lo, hi) of `total` concatenated items (multiples of the wave size).
+// How consumers divide a queue.  Round robin (block_chunks with rr set, and per wave in k_extend_carry): chunks of consecutive
+// positions dealt in turn, so every block sees paths from all over the image and the blocks, which all run at once, finish
+// together — with one contiguous share per block the CUs that drew cheap image regions idle at the end.  Contiguous (block_share):
+// one share [lo, hi) per block (multiples of the wave size); a block then stays within one image region, which keeps its L1
+// working set small when the scene is read from global memory.  The host picks per kernel (rt_render_device).
+struct ChunkLoop { uint32_t start, end, stride; };
+__device__ __forceinline__ void block_share(uint32_t total, uint32_t &lo, uint32_t &hi);
+// Loop bounds of a round-based consumer: round-robin chunks (rr != 0) or the block's contiguous share.
+__device__ __forceinline__ ChunkLoop block_chunks(uint32_t total, int rr) {
+    ChunkLoop c;
+    if (rr) { c.start = blockIdx.x * RT_BLOCK; c.end = total; c.stride = gridDim.x * RT_BLOCK; }
+    else { uint32_t lo, hi; block_share(total, lo, hi); c.start = lo; c.end = hi; c.stride = RT_BLOCK; }
+    return c;
+}
 __device__ __forceinline__ void block_share(uint32_t total, uint32_t &lo, uint32_t &hi) {
     uint32_t share = (total + gridDim.x - 1) / gridDim.x;
     share = (share + RT_WAVE - 1) & ~(uint32_t)(RT_WAVE - 1);
@@ -301,13 +315,13 @@ __device__ __forceinline__ void stage_pairs_lds(const DevScene &sc, float4 *s_pa
 }
 
 template <bool LDS_SCENE>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
+__global__ __launch_bounds__(RT_BLOCK, 5) void k_extend(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
                                                       uint32_t segcap, float4 *lbuf, BounceCounts *counts, BounceStats *stats, int *spill, int fast_walk) {
     __shared__ int s_stack[RT_LDS_STACK * RT_BLOCK];
     __shared__ float4 s_nodes[LDS_SCENE ? 2 * RT_LDS_SCENE_NODES : 1], s_slots[LDS_SCENE ? 3 * RT_LDS_SCENE_SLOTS : 1];
     // fast_walk on an LDS scene: the LDS copy holds pair records (k-th float4 of record r at s_nodes[k * 64 + r]) instead of nodes; the int
     // stack area then carries (node, tMin) entries for 8 levels, which the host guarantees to be enough
-    if (LDS_SCENE && fast_walk) {
+    if (LDS_SCENE && (fast_walk & 1)) {
         stage_pairs_lds(sc, s_nodes);
         for (int i = threadIdx.x; i < 3 * sc.n_slots; i += RT_BLOCK) s_slots[i] = sc.slots[i];
     } else if (LDS_SCENE) stage_scene_lds(sc, s_nodes, s_slots);
@@ -316,8 +330,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, RenderParams r
     BounceCounts *bc = counts + bounce;
     if (threadIdx.x < RT_NUM_CLASSES) s_cls[threadIdx.x] = 0;
     const uint32_t total = segment_prefix(bc->queue, s_prefix, s_wave);
-    uint32_t lo, hi;
-    block_share(total, lo, hi);
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_queue = total;
     // the shading kernels of this bounce append to segment blockIdx.x of the shadow queue and of the next queue
     if (threadIdx.x == 0) { bc->shadow[blockIdx.x] = 0; counts[bounce + 1].queue[blockIdx.x] = 0; }
@@ -325,11 +337,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, RenderParams r
     TravStack st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.reset();
     PairStackT<8, true> gst; gst.lds_i = pst.lds_i; gst.lds_t = pst.lds_t; gst.cap = sc.quad_stack_cap;
     gst.spill_i = spill + gtid; gst.spill_t = (float *)(spill + (size_t)gst.cap * nthreads) + gtid; gst.spill_stride = nthreads; gst.reset();
-    uint32_t seg = lo < hi ? segment_of(s_prefix, lo) : 0;
+    const ChunkLoop cl = block_chunks(total, fast_walk & 2);
+    uint32_t seg = cl.start < cl.end ? segment_of(s_prefix, cl.start) : 0;
     const uint32_t seg_base = blockIdx.x * segcap;
-    for (uint32_t base = lo; base < hi; base += RT_BLOCK) {
+    for (uint32_t base = cl.start; base < cl.end; base += cl.stride) {
         uint32_t g = base + threadIdx.x;
-        bool active = g < hi;
+        bool active = g < cl.end;
         int cls = -1;
         uint32_t i = 0;
         if (active) {
@@ -340,11 +353,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, RenderParams r
             int depth = state & 0xFFFF; bool spec = (state >> 16) & 1;
             HitRec h; uint32_t c0 = 0, c1 = 0;
             bool found;
-            if (LDS_SCENE && fast_walk) {
+            if (LDS_SCENE && (fast_walk & 1)) {
                 LaneTrav L = {};
                 trace_one<false, RT_LDS_SCENE_NODES / 2>(sc, s_nodes, s_slots, o, d, RT_INF, pst, L);
                 found = L.found; h.slot = L.found ? L.hitSlot : -1; h.t = L.tmax; h.b0 = L.b0; h.b1 = L.b1; h.b2 = L.b2;
-            } else if (!LDS_SCENE && fast_walk) {
+            } else if (!LDS_SCENE && (fast_walk & 1)) {
                 LaneTrav L = {};
                 trace_one<false, 1, true>(sc, sc.quads, sc.slots, o, d, RT_INF, gst, L);
                 found = L.found; h.slot = L.found ? L.hitSlot : -1; h.t = L.tmax; h.b0 = L.b0; h.b1 = L.b1; h.b2 = L.b2;
@@ -408,15 +421,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_carry(DevScene sc, RenderPa
     BounceCounts *bc = counts + bounce;
     if (threadIdx.x < RT_NUM_CLASSES) s_cls[threadIdx.x] = 0;
     const uint32_t total = segment_prefix(bc->queue, s_prefix, s_wave);
-    uint32_t lo, hi;
-    block_share(total, lo, hi);
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_queue = total;
     if (threadIdx.x == 0) { bc->shadow[blockIdx.x] = 0; counts[bounce + 1].queue[blockIdx.x] = 0; }
-    const uint32_t wave = threadIdx.x / RT_WAVE;
-    const uint32_t per = (((hi - lo) + RT_BLOCK / RT_WAVE - 1) / (RT_BLOCK / RT_WAVE) + RT_WAVE - 1) & ~(uint32_t)(RT_WAVE - 1);
-    const uint32_t w_lo = lo + wave * per < hi ? lo + wave * per : hi, w_hi = w_lo + per < hi ? w_lo + per : hi;
-    uint32_t w_next = w_lo;
-    uint32_t seg = w_lo < w_hi ? segment_of(s_prefix, w_lo) : 0;      // per-lane cursor; a lane's positions only grow
+    // Work is dealt out in chunks of 64 queue positions, round robin over all waves of the grid: wave w takes chunks w, w + W,
+    // w + 2W, ...  Every wave then sees rays from all over the image, so the waves (and with them the blocks, which all run at
+    // once) finish together; contiguous shares left the CUs that drew cheap image regions idle at the end.
+    const uint32_t n_waves = gridDim.x * (RT_BLOCK / RT_WAVE), gwave = blockIdx.x * (RT_BLOCK / RT_WAVE) + threadIdx.x / RT_WAVE;
+    const uint32_t n_chunks = (total + RT_WAVE - 1) / RT_WAVE;
+    const uint32_t w_hi = (gwave < n_chunks ? (n_chunks - gwave + n_waves - 1) / n_waves : 0) * RT_WAVE;   // this wave's positions: logical [0, w_hi)
+    uint32_t w_next = 0;
+    uint32_t seg = 0;                                                 // per-lane cursor; a lane's positions only grow
     const uint32_t seg_base = blockIdx.x * segcap;
     LaneTrav L = {};
     L.mode = RT_LANE_DONE; L.hitSlot = -1;
@@ -470,8 +484,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_carry(DevScene sc, RenderPa
         // ---- take the next rays of the wave's range
         const uint64_t im = __ballot(!busy);
         const uint32_t left = w_hi - w_next, nidle = (uint32_t)__popcll(im), take = nidle < left ? nidle : left;
-        if (!busy && prefix_in_mask(im) < take) {
-            uint32_t g = w_next + prefix_in_mask(im);
+        const uint32_t ln = w_next + prefix_in_mask(im);                  // logical position -> queue position
+        const uint32_t g = ((ln / RT_WAVE) * n_waves + gwave) * RT_WAVE + (ln & (RT_WAVE - 1));
+        if (!busy && prefix_in_mask(im) < take && g < total) {
             while (g >= s_prefix[seg + 1]) seg++;
             cur_i = seg * segcap + (g - s_prefix[seg]);
             F3 o = f3(q.ox[cur_i], q.oy[cur_i], q.oz[cur_i]), d = f3(q.dx[cur_i], q.dy[cur_i], q.dz[cur_i]);
@@ -752,13 +767,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc_in, RenderParams
     // continue this block's segments where the previous class kernel of this bounce left them
     if (threadIdx.x == 0) { s_out[0] = bc->shadow[blockIdx.x]; s_out[1] = counts[bounce + 1].queue[blockIdx.x]; }
     const uint32_t total = segment_prefix(bc->cls[MAT], s_prefix, s_wave);
-    uint32_t lo, hi;
-    block_share(total, lo, hi);
-    uint32_t seg = lo < hi ? segment_of(s_prefix, lo) : 0;
+    const ChunkLoop cl = block_chunks(total, rp.rr_shade);
+    uint32_t seg = cl.start < cl.end ? segment_of(s_prefix, cl.start) : 0;
     const uint32_t seg_base = blockIdx.x * segcap;
-    for (uint32_t base = lo; base < hi; base += RT_BLOCK) {
+    for (uint32_t base = cl.start; base < cl.end; base += cl.stride) {
         uint32_t j = base + threadIdx.x;
-        bool active = j < hi;
+        bool active = j < cl.end;
         bool has_shadow = false, has_next = false;
         uint32_t id = 0, nstate = 0;
         F3 so = f3(0, 0, 0), sd = f3(0, 0, 0), sc3 = f3(0, 0, 0), no = f3(0, 0, 0), nd = f3(0, 0, 0), nT = f3(0, 0, 0);
@@ -922,7 +936,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, Sh
     __shared__ float4 s_nodes[LDS_SCENE ? 2 * RT_LDS_SCENE_NODES : 1], s_slots[LDS_SCENE ? 3 * RT_LDS_SCENE_SLOTS : 1];
     // fast_walk on an LDS scene: the LDS copy holds pair records (k-th float4 of record r at s_nodes[k * 64 + r]) instead of nodes; the int
     // stack area then carries (node, tMin) entries for 8 levels, which the host guarantees to be enough
-    if (LDS_SCENE && fast_walk) {
+    if (LDS_SCENE && (fast_walk & 1)) {
         stage_pairs_lds(sc, s_nodes);
         for (int i = threadIdx.x; i < 3 * sc.n_slots; i += RT_BLOCK) s_slots[i] = sc.slots[i];
     } else if (LDS_SCENE) stage_scene_lds(sc, s_nodes, s_slots);
@@ -930,25 +944,26 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, Sh
     __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE];
     BounceCounts *bc = counts + bounce;
     const uint32_t total = segment_prefix(bc->shadow, s_prefix, s_wave);
-    uint32_t lo, hi;
-    block_share(total, lo, hi);
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_shadow = total;
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     TravStack st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.reset();
     PairStackT<8, true> gst; gst.lds_i = pst.lds_i; gst.lds_t = pst.lds_t; gst.cap = sc.quad_stack_cap;
     gst.spill_i = spill + gtid; gst.spill_t = (float *)(spill + (size_t)gst.cap * nthreads) + gtid; gst.spill_stride = nthreads; gst.reset();
-    uint32_t seg = lo < hi ? segment_of(s_prefix, lo) : 0;
-    for (uint32_t g = lo + threadIdx.x; g < hi; g += RT_BLOCK) {
+    const ChunkLoop cl = block_chunks(total, fast_walk & 2);
+    uint32_t seg = cl.start < cl.end ? segment_of(s_prefix, cl.start) : 0;
+    for (uint32_t base = cl.start; base < cl.end; base += cl.stride) {
+        uint32_t g = base + threadIdx.x;
+        if (g >= cl.end) break;
         while (g >= s_prefix[seg + 1]) seg++;
         uint32_t i = seg * segcap + (g - s_prefix[seg]);
         F3 o = f3(sq.ox[i], sq.oy[i], sq.oz[i]), d = f3(sq.dx[i], sq.dy[i], sq.dz[i]);
         HitRec h; uint32_t c0 = 0, c1 = 0;
         bool occluded;   // tMax = 1 - ShadowEpsilon
-        if (LDS_SCENE && fast_walk) {
+        if (LDS_SCENE && (fast_walk & 1)) {
             LaneTrav L = {};
             trace_one<true, RT_LDS_SCENE_NODES / 2>(sc, s_nodes, s_slots, o, d, 1.f - 0.0001f, pst, L);
             occluded = L.found;
-        } else if (!LDS_SCENE && fast_walk) {
+        } else if (!LDS_SCENE && (fast_walk & 1)) {
             LaneTrav L = {};
             trace_one<true, 1, true>(sc, sc.quads, sc.slots, o, d, 1.f - 0.0001f, gst, L);
             occluded = L.found;
@@ -1693,9 +1708,10 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     int nseg = env_int("RT_AMD_FRAME_BLOCKS_PER_CU", small_tree ? 5 : 4) * ncu;
     nseg = std::max(RT_BLOCK, std::min(RT_SEG_BLOCKS, nseg / RT_BLOCK * RT_BLOCK));
     // segment capacity: a block's share of the pass, plus room for the rounding of every class kernel's share
+    // (a block that takes chunks of RT_BLOCK round robin handles at most its even share rounded up to a chunk, once per class kernel)
     size_t share = (n_pass + nseg - 1) / nseg;
-    share = (share + RT_WAVE - 1) & ~(size_t)(RT_WAVE - 1);
-    size_t segcap = share + (size_t)RT_WAVE * RT_NUM_CLASSES;
+    share = (share + RT_BLOCK - 1) & ~(size_t)(RT_BLOCK - 1);
+    size_t segcap = share + (size_t)RT_BLOCK * (RT_NUM_CLASSES + 1);
     size_t cap = segcap * nseg;
     if (cap >= (1ull << 31)) { set_error(ctx, "rt_render: pass too large"); return -1; }
     if (cap > this_->ws_cap) {
@@ -1743,6 +1759,13 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     const int round_bounces = env_int("RT_AMD_FRAME_ROUND_BOUNCES", small_tree ? 1 << 20 : 1);
     const int round_pairs = (this_->interior_depth <= 8 && env_int("RT_AMD_ROUND_PAIRS", 1)) ? 1 : 0;
     const int round_quads = (this_->dev.quads && env_int("RT_AMD_ROUND_PAIRS", 1)) ? 1 : 0;
+    // Round-robin chunks or contiguous shares for the round-based kernels (block_chunks).  Measured at 800x800, 256 spp, Msamples/s,
+    // (extend, shade, shadow) round robin: helmet 353 (0,0,0), 421 (1,0,0), 403 (0,1,0), 411 (1,1,1), 422 (1,0,1); Cornell 1426, 1448,
+    // 1425, 1430, 1439; spheres 3194, 3221, 3212, 3193, 3275.  Traversal cost varies across the image, so the traversal kernels gain
+    // from dealing chunks out; the shading kernels read through index lists and do better on contiguous shares.
+    const int rr_extend = env_int("RT_AMD_RR_EXTEND", 1) ? 2 : 0;
+    const int rr_shadow = env_int("RT_AMD_RR_SHADOW", 1) ? 2 : 0;
+    rp.rr_shade = env_int("RT_AMD_RR_SHADE", 0);
     // incoherent bounces of LDS scenes: lanes carry long rays over and refill (k_extend_carry); camera rays stay round-based
     const int carry_from = env_int("RT_AMD_CARRY_FROM", 1);
     // shadow rays traced inside the shading kernels: scenes whose tree and tables both sit in LDS
@@ -1760,10 +1783,10 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                                        ucap, useg, lbuf, counts, bstats);
                 else if (lds_scene)
                     hipLaunchKernelGGL(k_extend<true>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
-                                       ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, round_pairs);
+                                       ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, round_pairs | rr_extend);
                 else
                     hipLaunchKernelGGL(k_extend<false>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
-                                       ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, round_quads);
+                                       ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, round_quads | rr_extend);
             } else if (walk_mode == RT_WALK_QUADS)
                 hipLaunchKernelGGL(k_extend_pl<RT_WALK_QUADS>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
                                    (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
@@ -1781,10 +1804,10 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                     if (frame_old || b < round_bounces) {
                         if (lds_scene)
                             hipLaunchKernelGGL(k_shadow<true>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
-                                               (int *)this_->d_spill.p, round_pairs);
+                                               (int *)this_->d_spill.p, round_pairs | rr_shadow);
                         else
                             hipLaunchKernelGGL(k_shadow<false>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
-                                               (int *)this_->d_spill.p, round_quads);
+                                               (int *)this_->d_spill.p, round_quads | rr_shadow);
                     } else if (walk_mode == RT_WALK_QUADS)       // the hit buffer's slot array is free once the shading kernels are done
                         hipLaunchKernelGGL(k_shadow_pl<RT_WALK_QUADS>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, hb.slot, useg, lbuf,
                                            counts, bstats, (int *)this_->d_spill.p);
