@@ -990,27 +990,41 @@ enum { RT_WALK_QUADS = 1, RT_WALK_PAIRS = 2 };
 
 struct RayArrays { const float *ox, *oy, *oz, *dx, *dy, *dz; };
 
-// Traverse the rays at concatenated positions [lo, hi) of a segmented queue; sink(i, L) receives each finished ray
+// The waves of the grid take the chunks of RT_WAVE consecutive queue positions round robin (wave w: chunks w, w + W, ...; see
+// block_share for why).  WaveChunks maps a wave's k-th chunk to its first queue position.
+struct WaveChunks {
+    uint32_t n_waves, gwave, n_mine, total;
+    __device__ __forceinline__ WaveChunks(uint32_t total_) : total(total_) {
+        n_waves = gridDim.x * (RT_BLOCK / RT_WAVE); gwave = blockIdx.x * (RT_BLOCK / RT_WAVE) + threadIdx.x / RT_WAVE;
+        const uint32_t n_chunks = (total + RT_WAVE - 1) / RT_WAVE;
+        n_mine = gwave < n_chunks ? (n_chunks - gwave + n_waves - 1) / n_waves : 0;
+    }
+    __device__ __forceinline__ uint32_t first(uint32_t k) const { return (k * n_waves + gwave) * RT_WAVE; }
+};
+
+// Traverse this wave's chunks of the `total` concatenated positions of a segmented queue; sink(i, L) receives each finished ray
 // (i = its position in the queue arrays).  recs = pair or quad records (LDS or global), slots = leaf slots.
 template <bool ANY, int MODE, class Stack, class Sink>
-__device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *recs, const float4 *slots, RayArrays ra, float tmax0, uint32_t lo, uint32_t hi,
+__device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *recs, const float4 *slots, RayArrays ra, float tmax0, uint32_t total,
                                             const uint32_t *s_prefix, uint32_t segcap, Stack &st, float *s_ray, Sink sink) {
-    const uint32_t lane = lane_id(), wave = threadIdx.x / RT_WAVE;
-    const uint32_t per = (((hi - lo) + RT_BLOCK / RT_WAVE - 1) / (RT_BLOCK / RT_WAVE) + RT_WAVE - 1) & ~(uint32_t)(RT_WAVE - 1);
-    const uint32_t w_lo = lo + wave * per < hi ? lo + wave * per : hi, w_hi = w_lo + per < hi ? w_lo + per : hi;
-    uint32_t w_next = w_lo;
-    uint32_t seg = w_lo < w_hi ? segment_of(s_prefix, w_lo) : 0;      // per-lane cursor; a lane's positions only grow
+    const uint32_t lane = lane_id();
+    const WaveChunks wc(total);
+    uint32_t w_chunk = 0;                                             // chunks taken so far
+    uint32_t seg = 0;                                                 // per-lane cursor; a lane's positions only grow
     float p_ox = 0.f, p_oy = 0.f, p_oz = 0.f, p_dx = 0.f, p_dy = 0.f, p_dz = 1.f; uint32_t p_i = 0;   // the batch being prefetched
     uint32_t pf_count = 0;                                            // rays in the prefetch registers (wave-uniform)
     auto prefetch = [&]() {
-        pf_count = w_hi - w_next < RT_WAVE ? w_hi - w_next : RT_WAVE;
-        if (lane < pf_count) {
-            uint32_t g = w_next + lane;
-            while (g >= s_prefix[seg + 1]) seg++;
-            p_i = seg * segcap + (g - s_prefix[seg]);
-            p_ox = ra.ox[p_i]; p_oy = ra.oy[p_i]; p_oz = ra.oz[p_i]; p_dx = ra.dx[p_i]; p_dy = ra.dy[p_i]; p_dz = ra.dz[p_i];
+        pf_count = 0;
+        if (w_chunk < wc.n_mine) {
+            const uint32_t g0 = wc.first(w_chunk++);
+            pf_count = total - g0 < RT_WAVE ? total - g0 : RT_WAVE;
+            if (lane < pf_count) {
+                uint32_t g = g0 + lane;
+                while (g >= s_prefix[seg + 1]) seg++;
+                p_i = seg * segcap + (g - s_prefix[seg]);
+                p_ox = ra.ox[p_i]; p_oy = ra.oy[p_i]; p_oz = ra.oz[p_i]; p_dx = ra.dx[p_i]; p_dy = ra.dy[p_i]; p_dz = ra.dz[p_i];
+            }
         }
-        w_next += pf_count;
     };
     prefetch();
     uint32_t avail = 0, rd = 0;                                       // rays left in the LDS batch, read cursor (wave-uniform)
@@ -1080,8 +1094,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_pl(DevScene sc, RenderParam
     BounceCounts *bc = counts + bounce;
     if (threadIdx.x < RT_NUM_CLASSES) s_cls[threadIdx.x] = 0;
     const uint32_t total = segment_prefix(bc->queue, s_prefix, s_wave);
-    uint32_t lo, hi;
-    block_share(total, lo, hi);
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_queue = total;
     // the shading kernels of this bounce append to segment blockIdx.x of the shadow queue and of the next queue
     if (threadIdx.x == 0) { bc->shadow[blockIdx.x] = 0; counts[bounce + 1].queue[blockIdx.x] = 0; }
@@ -1090,18 +1102,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_pl(DevScene sc, RenderParam
     st.cap = MODE == RT_WALK_QUADS ? sc.quad_stack_cap : RT_MAX_STACK;
     st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     RayArrays ra = {q.ox, q.oy, q.oz, q.dx, q.dy, q.dz};
-    trace_share<false, MODE>(sc, recs, slots, ra, RT_INF, lo, hi, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE],
+    trace_share<false, MODE>(sc, recs, slots, ra, RT_INF, total, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE],
                              [&](uint32_t i, const LaneTrav &L) {
                                  hb.slot[i] = L.found ? L.hitSlot : -1; hb.t[i] = L.tmax; hb.b0[i] = L.b0; hb.b1[i] = L.b1; hb.b2[i] = L.b2;
                              });
     __threadfence_block();
     __syncthreads();
-    // second sweep, coalesced: emission / sky / termination (integrator.cpp:242-257) and class binning
-    uint32_t seg = lo < hi ? segment_of(s_prefix, lo) : 0;
+    // second sweep, coalesced, every wave over its own chunks: emission / sky / termination (integrator.cpp:242-257) and class binning
+    uint32_t seg = 0;
     const uint32_t seg_base = blockIdx.x * segcap;
-    for (uint32_t base = lo; base < hi; base += RT_BLOCK) {
-        uint32_t g = base + threadIdx.x;
-        bool active = g < hi;
+    const WaveChunks wc(total);
+    for (uint32_t k = 0; k < wc.n_mine; ++k) {
+        uint32_t g = wc.first(k) + lane_id();
+        bool active = g < total;
         int cls = -1;
         uint32_t i = 0;
         if (active) {
@@ -1159,8 +1172,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_pl(DevScene sc, int bounce,
     const float4 *recs = MODE == RT_WALK_QUADS ? sc.quads : sc.pairs, *slots = sc.slots;
     BounceCounts *bc = counts + bounce;
     const uint32_t total = segment_prefix(bc->shadow, s_prefix, s_wave);
-    uint32_t lo, hi;
-    block_share(total, lo, hi);
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_shadow = total;
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     PairStackT<RT_FRAME_RING> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
@@ -1168,12 +1179,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_pl(DevScene sc, int bounce,
     st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     RayArrays ra = {sq.ox, sq.oy, sq.oz, sq.dx, sq.dy, sq.dz};
     // tMax = 1 - ShadowEpsilon (interaction.h SpawnRayTo)
-    trace_share<true, MODE>(sc, recs, slots, ra, 1.f - 0.0001f, lo, hi, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE],
+    trace_share<true, MODE>(sc, recs, slots, ra, 1.f - 0.0001f, total, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE],
                             [&](uint32_t i, const LaneTrav &L) { occluded[i] = L.found ? 1 : 0; });
     __threadfence_block();
     __syncthreads();
-    uint32_t seg = lo < hi ? segment_of(s_prefix, lo) : 0;
-    for (uint32_t g = lo + threadIdx.x; g < hi; g += RT_BLOCK) {
+    uint32_t seg = 0;
+    const WaveChunks wc(total);
+    for (uint32_t k = 0; k < wc.n_mine; ++k) {
+        uint32_t g = wc.first(k) + lane_id();
+        if (g >= total) break;
         while (g >= s_prefix[seg + 1]) seg++;
         uint32_t i = seg * segcap + (g - s_prefix[seg]);
         if (!occluded[i]) {
