@@ -69,6 +69,7 @@ struct RenderParams {
     uint32_t k0, k1;
     uint32_t n_paths;
     int rr_shade;       // shading kernels take their chunks round robin (block_chunks)
+    int merge_mirror;   // mirror paths are binned with the matte ones and shaded by k_shade<RT_MAT_MATTE>
 };
 
 // ---------------------------------------------------------------- helpers --
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend(DevScene sc, RenderParam
                 L.x += q.tr[i] * add.x; L.y += q.tg[i] * add.y; L.z += q.tb[i] * add.z;
                 lbuf[id] = L;
             }
-            if (!terminal) cls = sc.materials[sc.slot_material[h.slot]].kind;
+            if (!terminal) { cls = sc.materials[sc.slot_material[h.slot]].kind; if (rp.merge_mirror && cls == RT_MAT_MIRROR) cls = RT_MAT_MATTE; }
         }
         // bin the path into the queue of its material class (one ballot per class present in the wave)
         for (int c = 0; c < RT_NUM_CLASSES; ++c) {
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_carry(DevScene sc, RenderPa
                 Lr.x += q.tr[i] * add.x; Lr.y += q.tg[i] * add.y; Lr.z += q.tb[i] * add.z;
                 lbuf[id] = Lr;
             }
-            if (!terminal) cls = sc.materials[sc.slot_material[slot]].kind;
+            if (!terminal) { cls = sc.materials[sc.slot_material[slot]].kind; if (rp.merge_mirror && cls == RT_MAT_MIRROR) cls = RT_MAT_MATTE; }
             busy = false;
         }
         if (__ballot(fin) != 0)
@@ -732,8 +733,9 @@ __device__ __forceinline__ void copy_words_to_lds(void *dst, const void *src, in
 // FUSE (LDS_TABLES scenes whose tree also fits the LDS walk): the shadow ray of next-event estimation is traced here, out of an
 // LDS copy of the pair records, instead of going through the shadow queue to k_shadow; the unoccluded light is added to
 // the path's radiance slot at once.  The tables live in dynamic LDS sized to the scene (shade_lds_bytes).
+// (matte and mirror are held at five waves per SIMD, which is also what their LDS allows; the heavier materials take the registers they need)
 template <int MAT, bool LDS_TABLES, bool FUSE>
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc_in, RenderParams rp, int bounce, PathQueue q, PathQueue qn, HitBuf hb, const uint32_t *cls_list,
+__global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIRROR || MAT == RT_MAT_METALROUGH) ? 5 : 4) void k_shade(DevScene sc_in, RenderParams rp, int bounce, PathQueue q, PathQueue qn, HitBuf hb, const uint32_t *cls_list,
                                                      uint32_t cap, uint32_t segcap, ShadowQueue sq, BounceCounts *counts, float4 *lbuf, BounceStats *stats) {
     static_assert(!FUSE || LDS_TABLES, "the fused shadow walk needs the LDS tables");
     __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE], s_out[2];
@@ -788,71 +790,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc_in, RenderParams
             const DevMaterial &m = sc.materials[sc.slot_material[slot]];
             SurfacePoint sp;
             surface_point(sc, slot, o, d, hb.t[i], hb.b0[i], hb.b1[i], hb.b2[i], material_needs_uv<MAT>(sc, m), sp);
-            Lobe lobe, lobe2;       // lobe2: only PlasticMaterial has a second lobe (BSDF::Add order: Lambert, then microfacet)
-            build_lobe<MAT>(sc, m, sp.u, sp.v, lobe);
-            lobe2.kind = 0;
-            if (MAT == RT_MAT_PLASTIC) {
-                build_plastic_gloss(sc, m, sp.u, sp.v, lobe2);
-                if (lobe.kind == 0) { lobe = lobe2; lobe2.kind = 0; }
-            }
-            const int nlobes = (MAT == RT_MAT_PLASTIC && lobe2.kind != 0) ? 2 : 1;
             uint32_t pixel = id / (uint32_t)rp.spb, sample = (uint32_t)rp.sample0 + id % (uint32_t)rp.spb;
             uint32_t a0 = pixel, a1 = sample, a2 = (uint32_t)depth, a3 = 0;   // {light pick, uLight.x, uLight.y, roulette}
             philox4x32(a0, a1, a2, a3, rp.k0, rp.k1);
-            // ---- next-event estimation: UniformSampleOneLight + EstimateDirect, integrator.cpp:53-102,259-264
-            if (lobe.kind != 0 && !lobe_is_specular(lobe.kind) && sc.n_lights > 0) {
-                int nL = sc.n_lights;
-                int ln = min((int)(u32_to_unit(a0) * nL), nL - 1);
-                float selPdf = 1.f / nL;
-                const DevLight &L = sc.lights[ln];
-                float u0 = u32_to_unit(a1), u1 = u32_to_unit(a2);
-                F3 p0 = f3(L.p0[0], L.p0[1], L.p0[2]), p1 = f3(L.p1[0], L.p1[1], L.p1[2]), p2 = f3(L.p2[0], L.p2[1], L.p2[2]);
-                float su0 = sqrtf(u0);
-                float lb0 = 1 - su0, lb1 = u1 * su0;                       // UniformSampleTriangle, sampling.cpp:108-111
-                F3 lp = (lb0 * p0 + lb1 * p1) + (1 - lb0 - lb1) * p2;      // Triangle::Sample, triangle.cpp:229-248
-                F3 lnrm = f3(L.n[0], L.n[1], L.n[2]);
-                if (L.has_n) {
-                    float w2 = 1 - lb0 - lb1;
-                    F3 ns = (lb0 * f3(L.vn[0], L.vn[1], L.vn[2]) + lb1 * f3(L.vn[3], L.vn[4], L.vn[5])) + w2 * f3(L.vn[6], L.vn[7], L.vn[8]);
-                    if (dot3(lnrm, ns) < 0.f) lnrm = -lnrm;
-                }
-                float pdf = 1 / L.area;
-                F3 wi = lp - sp.p;                                          // Shape::Sample(ref,u,pdf), shape.cpp:20-31
-                if (lensq(wi) == 0) pdf = 0;
-                else {
-                    wi = normalize3(wi);
-                    pdf *= lensq(sp.p - lp) / fabsf(dot3(lnrm, -wi));
-                    if (isinf(pdf)) pdf = 0.f;
-                }
-                F3 Li = f3(0.f, 0.f, 0.f);                                  // DiffuseAreaLight::Sample_Li, light.cpp:43-54
-                if (pdf == 0 || lensq(lp - sp.p) == 0) pdf = 0;
-                else {
-                    wi = normalize3(lp - sp.p);
-                    if (L.two_sided || dot3(lnrm, -wi) > 0) Li = f3(L.Le[0], L.Le[1], L.Le[2]);
-                }
-                if (pdf > 0 && !black3(Li)) {
-                    // BSDF::f(wo, wi, ALL & ~SPECULAR) * AbsDot(wi, ns), reflection.cpp:140-152
-                    F3 wol = to_local(sp, sp.wo), wil = to_local(sp, wi);
-                    F3 f = f3(0.f, 0.f, 0.f);
-                    if (wol.z != 0) {
-                        bool reflect = dot3(wi, sp.n) * dot3(sp.wo, sp.n) > 0;
-                        if (reflect) {
-                            f = lobe_f(lobe, wol, wil);
-                            if (nlobes == 2) f = f + lobe_f(lobe2, wol, wil);
-                        }
-                    }
-                    float ad = fabsf(dot3(wi, sp.n));
-                    f = f3(f.x * ad, f.y * ad, f.z * ad);
-                    if (!black3(f)) {
-                        F3 origin = offset_ray_origin(sp.p, sp.n, lp - sp.p);     // Interaction::SpawnRayTo, interaction.h:27-32
-                        F3 target = offset_ray_origin(lp, lnrm, origin - lp);
-                        F3 Ld = cdiv(cdiv(f * Li, pdf), selPdf);
-                        has_shadow = true; so = origin; sd = target - origin; sc3 = T * Ld;
-                    }
-                }
-            }
-            // ---- BSDF sampling, integrator.cpp:265-279 + BSDF::Sample_f reflection.cpp:173-217
-            if (lobe.kind != 0) {
+            // ---- BSDF sampling, integrator.cpp:265-279 + BSDF::Sample_f reflection.cpp:173-217 (as a lambda: the matte kernel runs it
+            // a second time, specialised for a mirror lobe, when mirror paths ride in its list)
+            auto sample_bsdf = [&](const Lobe &lobe, const Lobe &lobe2, const int nlobes) {
                 uint32_t b0 = pixel, b1 = sample, b2 = (uint32_t)depth, b3 = 1;   // {bsdf.x, bsdf.y, -, -}
                 philox4x32(b0, b1, b2, b3, rp.k0, rp.k1);
                 // BSDF::Sample_f: component min(floor(u0 * n), n - 1), u0 remapped (reflection.cpp:176-190)
@@ -895,6 +838,76 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc_in, RenderParams
                         }
                     }
                 }
+            };
+            // Mirror paths that k_extend binned with the matte ones (RenderParams::merge_mirror): MirrorMaterial has one specular lobe,
+            // so there is no next-event estimation and the whole shading is one reflection (material.cpp:12-20, reflection.cpp:62-68).
+            // Their own launch read its short index list with sparse gathers and cost 4 % of a Cornell frame.
+            if (MAT == RT_MAT_MATTE && rp.merge_mirror && m.kind == RT_MAT_MIRROR) {
+                Lobe lm, none; none.kind = 0;
+                build_lobe<RT_MAT_MIRROR>(sc, m, sp.u, sp.v, lm);
+                if (lm.kind != 0) sample_bsdf(lm, none, 1);
+            } else {
+                Lobe lobe, lobe2;       // lobe2: only PlasticMaterial has a second lobe (BSDF::Add order: Lambert, then microfacet)
+                build_lobe<MAT>(sc, m, sp.u, sp.v, lobe);
+                lobe2.kind = 0;
+                if (MAT == RT_MAT_PLASTIC) {
+                    build_plastic_gloss(sc, m, sp.u, sp.v, lobe2);
+                    if (lobe.kind == 0) { lobe = lobe2; lobe2.kind = 0; }
+                }
+                const int nlobes = (MAT == RT_MAT_PLASTIC && lobe2.kind != 0) ? 2 : 1;
+                // ---- next-event estimation: UniformSampleOneLight + EstimateDirect, integrator.cpp:53-102,259-264
+                if (lobe.kind != 0 && !lobe_is_specular(lobe.kind) && sc.n_lights > 0) {
+                    int nL = sc.n_lights;
+                    int ln = min((int)(u32_to_unit(a0) * nL), nL - 1);
+                    float selPdf = 1.f / nL;
+                    const DevLight &L = sc.lights[ln];
+                    float u0 = u32_to_unit(a1), u1 = u32_to_unit(a2);
+                    F3 p0 = f3(L.p0[0], L.p0[1], L.p0[2]), p1 = f3(L.p1[0], L.p1[1], L.p1[2]), p2 = f3(L.p2[0], L.p2[1], L.p2[2]);
+                    float su0 = sqrtf(u0);
+                    float lb0 = 1 - su0, lb1 = u1 * su0;                       // UniformSampleTriangle, sampling.cpp:108-111
+                    F3 lp = (lb0 * p0 + lb1 * p1) + (1 - lb0 - lb1) * p2;      // Triangle::Sample, triangle.cpp:229-248
+                    F3 lnrm = f3(L.n[0], L.n[1], L.n[2]);
+                    if (L.has_n) {
+                        float w2 = 1 - lb0 - lb1;
+                        F3 ns = (lb0 * f3(L.vn[0], L.vn[1], L.vn[2]) + lb1 * f3(L.vn[3], L.vn[4], L.vn[5])) + w2 * f3(L.vn[6], L.vn[7], L.vn[8]);
+                        if (dot3(lnrm, ns) < 0.f) lnrm = -lnrm;
+                    }
+                    float pdf = 1 / L.area;
+                    F3 wi = lp - sp.p;                                          // Shape::Sample(ref,u,pdf), shape.cpp:20-31
+                    if (lensq(wi) == 0) pdf = 0;
+                    else {
+                        wi = normalize3(wi);
+                        pdf *= lensq(sp.p - lp) / fabsf(dot3(lnrm, -wi));
+                        if (isinf(pdf)) pdf = 0.f;
+                    }
+                    F3 Li = f3(0.f, 0.f, 0.f);                                  // DiffuseAreaLight::Sample_Li, light.cpp:43-54
+                    if (pdf == 0 || lensq(lp - sp.p) == 0) pdf = 0;
+                    else {
+                        wi = normalize3(lp - sp.p);
+                        if (L.two_sided || dot3(lnrm, -wi) > 0) Li = f3(L.Le[0], L.Le[1], L.Le[2]);
+                    }
+                    if (pdf > 0 && !black3(Li)) {
+                        // BSDF::f(wo, wi, ALL & ~SPECULAR) * AbsDot(wi, ns), reflection.cpp:140-152
+                        F3 wol = to_local(sp, sp.wo), wil = to_local(sp, wi);
+                        F3 f = f3(0.f, 0.f, 0.f);
+                        if (wol.z != 0) {
+                            bool reflect = dot3(wi, sp.n) * dot3(sp.wo, sp.n) > 0;
+                            if (reflect) {
+                                f = lobe_f(lobe, wol, wil);
+                                if (nlobes == 2) f = f + lobe_f(lobe2, wol, wil);
+                            }
+                        }
+                        float ad = fabsf(dot3(wi, sp.n));
+                        f = f3(f.x * ad, f.y * ad, f.z * ad);
+                        if (!black3(f)) {
+                            F3 origin = offset_ray_origin(sp.p, sp.n, lp - sp.p);     // Interaction::SpawnRayTo, interaction.h:27-32
+                            F3 target = offset_ray_origin(lp, lnrm, origin - lp);
+                            F3 Ld = cdiv(cdiv(f * Li, pdf), selPdf);
+                            has_shadow = true; so = origin; sd = target - origin; sc3 = T * Ld;
+                        }
+                    }
+                }
+                if (lobe.kind != 0) sample_bsdf(lobe, lobe2, nlobes);
             }
         }
         if (FUSE) {            // bvh.cpp:284-320 on the spot; tMax = 1 - ShadowEpsilon (interaction.h:27-32)
@@ -1149,7 +1162,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_pl(DevScene sc, RenderParam
                 Lr.x += q.tr[i] * add.x; Lr.y += q.tg[i] * add.y; Lr.z += q.tb[i] * add.z;
                 lbuf[id] = Lr;
             }
-            if (!terminal) cls = sc.materials[sc.slot_material[slot]].kind;
+            if (!terminal) { cls = sc.materials[sc.slot_material[slot]].kind; if (rp.merge_mirror && cls == RT_MAT_MIRROR) cls = RT_MAT_MATTE; }
         }
         for (int c = 0; c < RT_NUM_CLASSES; ++c) {
             bool mine = (cls == c);
@@ -1780,6 +1793,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     const int rr_extend = env_int("RT_AMD_RR_EXTEND", 1) ? 2 : 0;
     const int rr_shadow = env_int("RT_AMD_RR_SHADOW", 1) ? 2 : 0;
     rp.rr_shade = env_int("RT_AMD_RR_SHADE", 0);
+    rp.merge_mirror = (this_->classes[RT_MAT_MATTE] && this_->classes[RT_MAT_MIRROR] && env_int("RT_AMD_MERGE_MIRROR", 1)) ? 1 : 0;
     // incoherent bounces of LDS scenes: lanes carry long rays over and refill (k_extend_carry); camera rays stay round-based
     const int carry_from = env_int("RT_AMD_CARRY_FROM", 1);
     // shadow rays traced inside the shading kernels: scenes whose tree and tables both sit in LDS
@@ -1809,7 +1823,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                                    (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
             if (b < o->max_depth) {
                 if (this_->classes[RT_MAT_MATTE]) launch_shade<RT_MAT_MATTE>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
-                if (this_->classes[RT_MAT_MIRROR]) launch_shade<RT_MAT_MIRROR>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
+                if (this_->classes[RT_MAT_MIRROR] && !rp.merge_mirror) launch_shade<RT_MAT_MIRROR>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
                 if (this_->classes[RT_MAT_GLASS]) launch_shade<RT_MAT_GLASS>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
                 if (this_->classes[RT_MAT_METAL]) launch_shade<RT_MAT_METAL>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
                 if (this_->classes[RT_MAT_PLASTIC]) launch_shade<RT_MAT_PLASTIC>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
