@@ -57,6 +57,43 @@ def test_traversal_bit_exact_vs_oracle_random_rays(name, lo, hi, device_scene, o
     assert np.array_equal(device_scene(name, param).trace_any(o, d, tmax), oracle_scene(name, param).trace_any(o, d, tmax))
 
 
+def test_traversal_full_size_soup(gpu_ctx):
+    """The roofline configuration at its full size (10 M triangles, ~20 M nodes): closest hits bit-exact with the oracle on a
+    sample of incoherent rays, any-hit consistent with them, and the work counters of the counting kernel (what bench.py turns into
+    algorithmic bytes) equal to the oracle's per-ray counts of slab and triangle tests in reference order."""
+    torch = pytest.importorskip("torch")
+    import oracle_lib as ol
+    hs = ra.HostScene("soup", 10_000_000)
+    ds = ra.DeviceScene(gpu_ctx, hs.desc_ptr)
+    osc = ol.OracleScene(hs.desc_ptr)
+    rng = np.random.default_rng(7)
+    n = 1 << 17
+    o = rng.uniform(0, 100, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tmax = np.full(n, np.inf, np.float32)
+    prim, t, b = ds.trace_closest(o, d, tmax)
+    p2, t2, b2, nodes, tests = osc.trace_closest(o, d, tmax)
+    assert np.array_equal(prim, p2) and np.array_equal(t.view(np.uint32), t2.view(np.uint32))
+    assert 0.6 < (prim >= 0).mean() < 0.95
+    # any-hit with tMax just beyond / just short of the closest hit
+    hit = prim >= 0
+    far = np.where(hit, t * np.float32(1.001), np.float32(50)).astype(np.float32)
+    near = np.where(hit, t * np.float32(0.999), np.float32(50)).astype(np.float32)
+    assert np.array_equal(ds.trace_any(o, d, far), osc.trace_any(o, d, far))
+    assert np.array_equal(ds.trace_any(o, d, near), osc.trace_any(o, d, near))
+    assert np.all(ds.trace_any(o, d, far)[hit] == 1)
+    # counters, device-resident SoA rays as bench.py passes them
+    rays = torch.from_numpy(np.concatenate([o.T, d.T, tmax[None]], axis=0).copy()).cuda().contiguous()
+    hits = torch.empty((4, n), dtype=torch.float32, device="cuda")
+    st = ds.trace_closest_device(n, rays.data_ptr(), hits.data_ptr(), repeats=1, count_work=True)
+    torch.cuda.synchronize()
+    assert st.nodes_visited == int(nodes.sum()) and st.prims_tested == int(tests.sum())
+    assert np.array_equal(hits[0].view(torch.int32).cpu().numpy(), prim)
+    assert np.array_equal(hits[1].cpu().numpy().view(np.uint32), t.view(np.uint32))
+    assert 150 < nodes.mean() < 600          # deep tree, incoherent rays: the HBM-bound regime
+    ds.close(); osc.close(); hs.close()
+
+
 @pytest.mark.parametrize("name", ["cornell", "sphere1", "helmet"])
 def test_traversal_rays_on_box_planes(name, device_scene, oracle_scene, host_scene):
     """Origins ON bounding planes of tree nodes with directions that have zero components: 0 * inf = NaN inside the slab
