@@ -3,15 +3,19 @@
 // Pipeline for one pass over N = pixels x samples-in-pass camera paths (all state stays in HBM):
 //   k_raygen            camera rays, Philox film jitter                       camera.cpp:52-58, stratified.cpp:4-29
 //   per bounce b = 0..maxDepth:
-//     k_extend          closest-hit BVH traversal + path logic (emission, sky, termination),
-//                       appends the path to the queue of its material class     bvh.cpp:247-282, integrator.cpp:241-257
-//     k_shade<MAT>      one launch per material class present in the scene: BSDF build, next-event
-//                       estimation (-> compacted shadow queue), BSDF sampling, Russian roulette
-//                       (-> compacted next-bounce queue)                      integrator.cpp:258-280, material.cpp, reflection.cpp
-//     k_shadow          any-hit traversal of the shadow queue, adds unoccluded light  bvh.cpp:284-320, light.cpp:19-21
+//     k_extend          closest-hit BVH traversal + path logic (emission, sky, termination), appends the path to the
+//                       index list of its material class                      bvh.cpp:247-282, integrator.cpp:241-257
+//                       variants: k_extend (one ray per lane per round), k_extend_carry (small scenes walked out of LDS:
+//                       finished lanes take new rays every two rounds), k_extend_pl (persistent lanes, large trees)
+//     k_shade<MAT>      one launch per material class present in the scene: BSDF build, next-event estimation, BSDF
+//                       sampling, Russian roulette (-> compacted next-bounce queue).  The shadow ray goes to a compacted
+//                       shadow queue, or — scenes that fit LDS — is traced on the spot.
+//                                                                             integrator.cpp:258-280, material.cpp, reflection.cpp
+//     k_shadow          any-hit traversal of the shadow queue, adds unoccluded light (k_shadow / k_shadow_pl; not launched when
+//                       the shading kernels trace their own shadow rays)       bvh.cpp:284-320, light.cpp:19-21
 //   k_accumulate        per-pixel sum of the pass's path radiances into the frame's sum buffer  integrator.cpp:324-337
-// Queues are compacted with wave ballots + one atomic per wave; no scattered float atomics are used:
-// every path owns one float4 slot of radiance that only its own lane updates.
+// Queues are segmented (one segment per producer block, block-local LDS counters, no global atomics on the data path); no
+// scattered float atomics are used: every path owns one float4 slot of radiance that only its own lane updates.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
