@@ -1801,7 +1801,9 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     // incoherent bounces of LDS scenes: lanes carry long rays over and refill (k_extend_carry); camera rays stay round-based
     const int carry_from = env_int("RT_AMD_CARRY_FROM", 1);
     // shadow rays traced inside the shading kernels: scenes whose tree and tables both sit in LDS
-    const bool fuse_shadow = lds_scene && round_pairs && !frame_old && shade_tables_in_lds(this_->dev) && env_int("RT_AMD_FUSE_SHADOW", 1) != 0;
+    // (only while five blocks of the fused kernel still share a CU's 160 KB of LDS: 25.6 KB static + the scene's tables <= 32 KB)
+    const bool fuse_shadow = lds_scene && round_pairs && !frame_old && shade_tables_in_lds(this_->dev) && shade_lds_bytes(this_->dev) <= 6400 &&
+                             env_int("RT_AMD_FUSE_SHADOW", 1) != 0;
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
         int cur = std::min(spb, o->sample_end - s0);
         rp.spb = cur; rp.sample0 = s0; rp.n_paths = (uint32_t)(npix * (size_t)cur);
