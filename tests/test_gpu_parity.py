@@ -227,6 +227,19 @@ def test_render_within_reference_noise_floor(name, w, spp, device_scene, host_sc
     assert np.all(rmse < floor), (rmse, floor)
 
 
+@pytest.mark.parametrize("name", ["cornell", "spheres2"])
+def test_render_odd_image_shapes(name, device_scene, oracle_scene, host_scene):
+    """Non-square, one-pixel and sliver images, strata grids that are not square: same ray counts as the oracle and per-pixel agreement."""
+    for w, h, sx, sy in ((120, 80, 3, 2), (33, 77, 2, 5), (1, 1, 4, 4), (257, 3, 1, 1)):
+        cam = host_scene(name).camera(w, h)
+        opts = ra.make_opts(sx, sy)
+        img, st = device_scene(name).render(cam, opts)
+        ref, cnt = oracle_scene(name).render(cam, opts, mode=1)
+        assert img.shape == (h, w, 3) and st.samples == w * h * sx * sy
+        assert abs(int(st.rays_closest) - int(cnt["closest"])) <= 1e-4 * cnt["closest"] + 4
+        assert _rel_close(img, ref, 2e-3).mean() > 0.99, (w, h)
+
+
 def test_render_properties_at_full_size(device_scene, host_scene):
     """Size-independent properties on the headline configuration's resolution (Cornell 800x800):
     sample ranges add up (the multi-GPU split), passes of different sizes give the same image, runs are reproducible."""
