@@ -734,13 +734,16 @@ __device__ __forceinline__ void copy_words_to_lds(void *dst, const void *src, in
     for (int i = threadIdx.x; i < bytes / 4; i += RT_BLOCK) d[i] = g[i];
 }
 
-// FUSE (LDS_TABLES scenes whose tree also fits the LDS walk): the shadow ray of next-event estimation is traced here, out of an
+// TABLES: 0 = every table read from global memory, 1 = all of them in LDS (scenes of at most 64 slots), 2 = materials, textures and
+// lights in LDS, the per-slot tables in global memory.
+// FUSE (TABLES == 1 scenes whose tree also fits the LDS walk): the shadow ray of next-event estimation is traced here, out of an
 // LDS copy of the pair records, instead of going through the shadow queue to k_shadow; the unoccluded light is added to
 // the path's radiance slot at once.  The tables live in dynamic LDS sized to the scene (shade_lds_bytes).
 // (matte and mirror are held at five waves per SIMD, which is also what their LDS allows; the heavier materials take the registers they need)
-template <int MAT, bool LDS_TABLES, bool FUSE>
+template <int MAT, int TABLES, bool FUSE>
 __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIRROR || MAT == RT_MAT_METALROUGH) ? 5 : 4) void k_shade(DevScene sc_in, RenderParams rp, int bounce, PathQueue q, PathQueue qn, HitBuf hb, const uint32_t *cls_list,
                                                      uint32_t cap, uint32_t segcap, ShadowQueue sq, BounceCounts *counts, float4 *lbuf, BounceStats *stats) {
+    constexpr bool LDS_TABLES = TABLES == 1;
     static_assert(!FUSE || LDS_TABLES, "the fused shadow walk needs the LDS tables");
     __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE], s_out[2];
     extern __shared__ float4 s_dyn[];
@@ -763,6 +766,15 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
         copy_words_to_lds(t_lights, sc_in.lights, (int)sizeof(DevLight) * sc_in.n_lights);
         sc.slots = t_slots; sc.frames = t_frames; sc.slot_uv = t_uv; sc.slot_material = t_slot_mat; sc.materials = t_mats; sc.textures = t_tex;
         sc.lights = t_lights;
+    }
+    if (TABLES == 2) {     // larger scenes: only the tables that do not grow with the geometry (materials, textures, lights)
+        DevTexture *t_tex = (DevTexture *)s_dyn;
+        DevLight *t_lights = (DevLight *)(t_tex + sc_in.n_textures);
+        DevMaterial *t_mats = (DevMaterial *)(t_lights + sc_in.n_lights);
+        copy_words_to_lds(t_mats, sc_in.materials, (int)sizeof(DevMaterial) * sc_in.n_materials);
+        copy_words_to_lds(t_tex, sc_in.textures, (int)sizeof(DevTexture) * sc_in.n_textures);
+        copy_words_to_lds(t_lights, sc_in.lights, (int)sizeof(DevLight) * sc_in.n_lights);
+        sc.materials = t_mats; sc.textures = t_tex; sc.lights = t_lights;
     }
     if (FUSE)              // pair records, k-th float4 of record r at s_pairs[k * 64 + r] (the layout k_extend / k_shadow walk)
         stage_pairs_lds(sc_in, s_pairs);
@@ -1684,10 +1696,16 @@ static void bind_queue(PathQueue &q, void *base, size_t cap) {
 }
 
 extern "C++" {
-// Dynamic LDS of k_shade<.., LDS_TABLES = true>: the scene's shading tables.
+// Dynamic LDS of k_shade<.., TABLES = 1>: the scene's shading tables; small_tables_lds_bytes: TABLES = 2.
 static size_t shade_lds_bytes(const DevScene &d) {
     return (size_t)d.n_slots * (48 + 48 + 24 + 4) + (size_t)d.n_textures * sizeof(DevTexture) + (size_t)d.n_lights * sizeof(DevLight) +
            (size_t)d.n_materials * sizeof(DevMaterial);
+}
+static size_t small_tables_lds_bytes(const DevScene &d) {
+    return (size_t)d.n_textures * sizeof(DevTexture) + (size_t)d.n_lights * sizeof(DevLight) + (size_t)d.n_materials * sizeof(DevMaterial);
+}
+static bool small_tables_in_lds(const DevScene &d) {
+    return d.n_materials <= RT_LDS_TAB_MATERIALS && d.n_textures <= RT_LDS_TAB_TEXTURES && d.n_lights <= RT_LDS_TAB_LIGHTS && !env_int("RT_AMD_SHADE_GLOBAL_TABLES", 0);
 }
 static bool shade_tables_in_lds(const DevScene &d) {
     return d.n_slots <= RT_LDS_TAB_SLOTS && d.n_materials <= RT_LDS_TAB_MATERIALS && d.n_textures <= RT_LDS_TAB_TEXTURES && d.n_lights <= RT_LDS_TAB_LIGHTS &&
@@ -1699,13 +1717,16 @@ static void launch_shade(rt_scene *s, const RenderParams &rp, int bounce, const 
     const bool lds_tables = shade_tables_in_lds(s->dev);
     const size_t dyn = lds_tables ? shade_lds_bytes(s->dev) : 0;
     if (lds_tables && fuse_shadow)
-        hipLaunchKernelGGL((k_shade<MAT, true, true>), dim3(nseg), dim3(RT_BLOCK), dyn, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
+        hipLaunchKernelGGL((k_shade<MAT, 1, true>), dim3(nseg), dim3(RT_BLOCK), dyn, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
                            cap, segcap, sq, (BounceCounts *)s->d_counters.p, lbuf, stats);
     else if (lds_tables)
-        hipLaunchKernelGGL((k_shade<MAT, true, false>), dim3(nseg), dim3(RT_BLOCK), dyn, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
+        hipLaunchKernelGGL((k_shade<MAT, 1, false>), dim3(nseg), dim3(RT_BLOCK), dyn, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
                            cap, segcap, sq, (BounceCounts *)s->d_counters.p, lbuf, stats);
+    else if (small_tables_in_lds(s->dev))
+        hipLaunchKernelGGL((k_shade<MAT, 2, false>), dim3(nseg), dim3(RT_BLOCK), small_tables_lds_bytes(s->dev), s->ctx->stream, s->dev, rp, bounce, q, qn, hb,
+                           (const uint32_t *)s->d_cls.p, cap, segcap, sq, (BounceCounts *)s->d_counters.p, lbuf, stats);
     else
-        hipLaunchKernelGGL((k_shade<MAT, false, false>), dim3(nseg), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
+        hipLaunchKernelGGL((k_shade<MAT, 0, false>), dim3(nseg), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
                            cap, segcap, sq, (BounceCounts *)s->d_counters.p, lbuf, stats);
 }
 }  // extern "C++"
