@@ -42,7 +42,7 @@
 #define RT_SEG_PER_THREAD (RT_SEG_BLOCKS / RT_BLOCK)
 #define RT_FRAME_RING 8         // LDS ring entries per lane (node, tMin) of the frame kernels
 // The number of segments in use is the grid size of the frame kernels (gridDim.x, a multiple of RT_BLOCK): 1280 when every
-// kernel of the frame fits five blocks on a CU, 1024 when the persistent-lane kernels (four per CU) take part.
+// kernel of the frame fits five blocks on a CU, 1024 when one of them (the metal / plastic shading kernels on large trees) does not.
 
 // Queues are segmented: block b of a producer kernel appends only to segment b (positions
 // [b*segcap, b*segcap + count[b])) using a block-local LDS counter, and publishes count[b] with a plain store when it
@@ -1113,7 +1113,7 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
 }
 
 template <int MODE>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend_pl(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
+__global__ __launch_bounds__(RT_BLOCK, 5) void k_extend_pl(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
                                                          uint32_t segcap, float4 *lbuf, BounceCounts *counts, BounceStats *stats, int *spill) {
     __shared__ int s_si[RT_FRAME_RING * RT_BLOCK];
     __shared__ float s_st[RT_FRAME_RING * RT_BLOCK];
@@ -1192,7 +1192,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_pl(DevScene sc, RenderParam
 }
 
 template <int MODE>
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow_pl(DevScene sc, int bounce, ShadowQueue sq, int *occluded, uint32_t segcap, float4 *lbuf, BounceCounts *counts,
+__global__ __launch_bounds__(RT_BLOCK, 5) void k_shadow_pl(DevScene sc, int bounce, ShadowQueue sq, int *occluded, uint32_t segcap, float4 *lbuf, BounceCounts *counts,
                                                          BounceStats *stats, int *spill) {
     __shared__ int s_si[RT_FRAME_RING * RT_BLOCK];
     __shared__ float s_st[RT_FRAME_RING * RT_BLOCK];
@@ -1754,10 +1754,12 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     int spb = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(S, 1), pool / npix));
     size_t n_pass = npix * (size_t)spb;
     if (n_pass >= (1ull << 31)) { set_error(ctx, "rt_render: pass too large"); return -1; }
-    // queue segments = grid of every frame kernel: five blocks per CU unless the persistent-lane kernels (four per CU) run
+    // queue segments = grid of every frame kernel: five blocks per CU where every kernel of the frame allows it
     const int ncu = std::max(1, ctx->n_cu);
     const bool small_tree = this_->dev.n_nodes <= 4096;
-    int nseg = env_int("RT_AMD_FRAME_BLOCKS_PER_CU", small_tree ? 5 : 4) * ncu;
+    // (the metal and plastic shading kernels need more than the 96 registers that five waves per SIMD leave each lane)
+    const bool five_fit = !this_->classes[RT_MAT_METAL] && !this_->classes[RT_MAT_PLASTIC];
+    int nseg = env_int("RT_AMD_FRAME_BLOCKS_PER_CU", (small_tree || five_fit) ? 5 : 4) * ncu;
     nseg = std::max(RT_BLOCK, std::min(RT_SEG_BLOCKS, nseg / RT_BLOCK * RT_BLOCK));
     // segment capacity: a block's share of the pass, plus room for the rounding of every class kernel's share
     // (a block that takes chunks of RT_BLOCK round robin handles at most its even share rounded up to a chunk, once per class kernel)
