@@ -436,6 +436,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_carry(DevScene sc, RenderPa
     const uint32_t w_hi = (gwave < n_chunks ? (n_chunks - gwave + n_waves - 1) / n_waves : 0) * RT_WAVE;   // this wave's positions: logical [0, w_hi)
     uint32_t w_next = 0;
     uint32_t seg = 0;                                                 // per-lane cursor; a lane's positions only grow
+    // (a wave with a single chunk has nothing to take over: it runs its rays to the end and hands in once, which keeps the launches
+    // of the near-empty late bounces short)
+    const int rounds = n_chunks <= n_waves ? 1 << 20 : RT_CARRY_ROUNDS;
     const uint32_t seg_base = blockIdx.x * segcap;
     LaneTrav L = {};
     L.mode = RT_LANE_DONE; L.hitSlot = -1;
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_carry(DevScene sc, RenderPa
         if (__ballot(busy) == 0) break;
         // ---- a few rounds of traversal for every lane that holds a ray
 #pragma unroll 1
-        for (int k = 0; k < RT_CARRY_ROUNDS; ++k) {
+        for (int k = 0; k < rounds; ++k) {
             while (L.mode == RT_LANE_WALK) {
                 uint32_t info; bool hv;
                 if (L.plain) lane_walk<false, true, RT_LDS_SCENE_NODES / 2>(s_nodes, L, pst, dummy, info, hv);
