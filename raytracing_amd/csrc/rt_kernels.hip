@@ -737,6 +737,142 @@ __device__ __forceinline__ void copy_words_to_lds(void *dst, const void *src, in
     for (int i = threadIdx.x; i < bytes / 4; i += RT_BLOCK) d[i] = g[i];
 }
 
+// What shading one path hands on: the shadow ray of next-event estimation with the radiance it carries if unoccluded, and the
+// next ray of the path with its throughput and state (depth | specular << 16).
+struct ShadeOut { bool has_shadow, has_next; uint32_t nstate; F3 so, sd, sc3, no, nd, nT; };
+
+// Shading of one path at its hit (integrator.cpp:258-280): BSDF of material class MAT, next-event estimation, BSDF sampling,
+// Russian roulette.  `sc` may point its tables at LDS copies.
+template <int MAT>
+__device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParams &rp, F3 o, F3 d, F3 T, uint32_t id, uint32_t state, int slot, float hit_t,
+                                           float hit_b0, float hit_b1, float hit_b2, ShadeOut &out) {
+    out.has_shadow = false; out.has_next = false; out.nstate = 0;
+    out.so = out.sd = out.sc3 = out.no = out.nd = out.nT = f3(0.f, 0.f, 0.f);
+    int depth = state & 0xFFFF;
+    const DevMaterial &m = sc.materials[sc.slot_material[slot]];
+    SurfacePoint sp;
+    surface_point(sc, slot, o, d, hit_t, hit_b0, hit_b1, hit_b2, material_needs_uv<MAT>(sc, m), sp);
+    uint32_t pixel = id / (uint32_t)rp.spb, sample = (uint32_t)rp.sample0 + id % (uint32_t)rp.spb;
+    uint32_t a0 = pixel, a1 = sample, a2 = (uint32_t)depth, a3 = 0;   // {light pick, uLight.x, uLight.y, roulette}
+    philox4x32(a0, a1, a2, a3, rp.k0, rp.k1);
+    // ---- BSDF sampling, integrator.cpp:265-279 + BSDF::Sample_f reflection.cpp:173-217 (as a lambda: the matte kernel runs it
+    // a second time, specialised for a mirror lobe, when mirror paths ride in its list)
+    auto sample_bsdf = [&](const Lobe &lobe, const Lobe &lobe2, const int nlobes) {
+        uint32_t b0 = pixel, b1 = sample, b2 = (uint32_t)depth, b3 = 1;   // {bsdf.x, bsdf.y, -, -}
+        philox4x32(b0, b1, b2, b3, rp.k0, rp.k1);
+        // BSDF::Sample_f: component min(floor(u0 * n), n - 1), u0 remapped (reflection.cpp:176-190)
+        float ub = u32_to_unit(b0), u1 = u32_to_unit(b1);
+        int comp = nlobes == 1 ? 0 : min((int)floorf(ub * nlobes), nlobes - 1);
+        float u0 = fminf(ub * nlobes - comp, RT_ONE_MINUS_EPS);
+        Lobe chosen = lobe, other = lobe2;
+        if (nlobes == 2 && comp == 1) { chosen = lobe2; other = lobe; }
+        F3 woW = -d;
+        F3 wol = to_local(sp, woW), wil; float pdf = 0.f;
+        F3 f = f3(0.f, 0.f, 0.f);
+        if (wol.z != 0) {
+            f = lobe_sample(chosen, wol, u0, u1, wil, pdf);
+            if (pdf == 0) f = f3(0.f, 0.f, 0.f);
+            else {
+                F3 wiW = to_world(sp, wil);
+                if (nlobes == 2) { pdf += lobe_pdf(other, wol, wil); pdf /= nlobes; }      // reflection.cpp:199-204
+                if (!lobe_is_specular(chosen.kind)) {
+                    bool reflect = dot3(wiW, sp.n) * dot3(woW, sp.n) > 0;
+                    f = f3(0.f, 0.f, 0.f);
+                    if (reflect) {
+                        f = lobe_f(lobe, wol, wil);
+                        if (nlobes == 2) f = f + lobe_f(lobe2, wol, wil);
+                    }
+                }
+                if (!black3(f) && pdf != 0.f) {
+                    float ad = fabsf(dot3(wiW, sp.n));
+                    F3 beta = cdiv(f3(f.x * ad, f.y * ad, f.z * ad), pdf);
+                    bool alive = true;
+                    if (depth > 3) {
+                        float qq = fmaxf(.05f, 1 - maxcomp3(beta));
+                        if (u32_to_unit(a3) < qq) alive = false;
+                        beta = cdiv(beta, 1 - qq);
+                    }
+                    if (alive) {
+                        out.has_next = true;
+                        out.no = offset_ray_origin(sp.p, sp.n, wiW); out.nd = wiW; out.nT = T * beta;
+                        out.nstate = (uint32_t)(depth + 1) | (lobe_is_specular(chosen.kind) ? (1u << 16) : 0u);
+                    }
+                }
+            }
+        }
+    };
+    // Mirror paths that k_extend binned with the matte ones (RenderParams::merge_mirror): MirrorMaterial has one specular lobe,
+    // out.so there is out.no next-event estimation and the whole shading is one reflection (material.cpp:12-20, reflection.cpp:62-68).
+    // Their own launch read its short index list with sparse gathers and cost 4 % of a Cornell frame.
+    if (MAT == RT_MAT_MATTE && rp.merge_mirror && m.kind == RT_MAT_MIRROR) {
+        Lobe lm, none; none.kind = 0;
+        build_lobe<RT_MAT_MIRROR>(sc, m, sp.u, sp.v, lm);
+        if (lm.kind != 0) sample_bsdf(lm, none, 1);
+    } else {
+        Lobe lobe, lobe2;       // lobe2: only PlasticMaterial has a second lobe (BSDF::Add order: Lambert, then microfacet)
+        build_lobe<MAT>(sc, m, sp.u, sp.v, lobe);
+        lobe2.kind = 0;
+        if (MAT == RT_MAT_PLASTIC) {
+            build_plastic_gloss(sc, m, sp.u, sp.v, lobe2);
+            if (lobe.kind == 0) { lobe = lobe2; lobe2.kind = 0; }
+        }
+        const int nlobes = (MAT == RT_MAT_PLASTIC && lobe2.kind != 0) ? 2 : 1;
+        // ---- next-event estimation: UniformSampleOneLight + EstimateDirect, integrator.cpp:53-102,259-264
+        if (lobe.kind != 0 && !lobe_is_specular(lobe.kind) && sc.n_lights > 0) {
+            int nL = sc.n_lights;
+            int ln = min((int)(u32_to_unit(a0) * nL), nL - 1);
+            float selPdf = 1.f / nL;
+            const DevLight &L = sc.lights[ln];
+            float u0 = u32_to_unit(a1), u1 = u32_to_unit(a2);
+            F3 p0 = f3(L.p0[0], L.p0[1], L.p0[2]), p1 = f3(L.p1[0], L.p1[1], L.p1[2]), p2 = f3(L.p2[0], L.p2[1], L.p2[2]);
+            float su0 = sqrtf(u0);
+            float lb0 = 1 - su0, lb1 = u1 * su0;                       // UniformSampleTriangle, sampling.cpp:108-111
+            F3 lp = (lb0 * p0 + lb1 * p1) + (1 - lb0 - lb1) * p2;      // Triangle::Sample, triangle.cpp:229-248
+            F3 lnrm = f3(L.n[0], L.n[1], L.n[2]);
+            if (L.has_n) {
+                float w2 = 1 - lb0 - lb1;
+                F3 ns = (lb0 * f3(L.vn[0], L.vn[1], L.vn[2]) + lb1 * f3(L.vn[3], L.vn[4], L.vn[5])) + w2 * f3(L.vn[6], L.vn[7], L.vn[8]);
+                if (dot3(lnrm, ns) < 0.f) lnrm = -lnrm;
+            }
+            float pdf = 1 / L.area;
+            F3 wi = lp - sp.p;                                          // Shape::Sample(ref,u,pdf), shape.cpp:20-31
+            if (lensq(wi) == 0) pdf = 0;
+            else {
+                wi = normalize3(wi);
+                pdf *= lensq(sp.p - lp) / fabsf(dot3(lnrm, -wi));
+                if (isinf(pdf)) pdf = 0.f;
+            }
+            F3 Li = f3(0.f, 0.f, 0.f);                                  // DiffuseAreaLight::Sample_Li, light.cpp:43-54
+            if (pdf == 0 || lensq(lp - sp.p) == 0) pdf = 0;
+            else {
+                wi = normalize3(lp - sp.p);
+                if (L.two_sided || dot3(lnrm, -wi) > 0) Li = f3(L.Le[0], L.Le[1], L.Le[2]);
+            }
+            if (pdf > 0 && !black3(Li)) {
+                // BSDF::f(wo, wi, ALL & ~SPECULAR) * AbsDot(wi, ns), reflection.cpp:140-152
+                F3 wol = to_local(sp, sp.wo), wil = to_local(sp, wi);
+                F3 f = f3(0.f, 0.f, 0.f);
+                if (wol.z != 0) {
+                    bool reflect = dot3(wi, sp.n) * dot3(sp.wo, sp.n) > 0;
+                    if (reflect) {
+                        f = lobe_f(lobe, wol, wil);
+                        if (nlobes == 2) f = f + lobe_f(lobe2, wol, wil);
+                    }
+                }
+                float ad = fabsf(dot3(wi, sp.n));
+                f = f3(f.x * ad, f.y * ad, f.z * ad);
+                if (!black3(f)) {
+                    F3 origin = offset_ray_origin(sp.p, sp.n, lp - sp.p);     // Interaction::SpawnRayTo, interaction.h:27-32
+                    F3 target = offset_ray_origin(lp, lnrm, origin - lp);
+                    F3 Ld = cdiv(cdiv(f * Li, pdf), selPdf);
+                    out.has_shadow = true; out.so = origin; out.sd = target - origin; out.sc3 = T * Ld;
+                }
+            }
+        }
+        if (lobe.kind != 0) sample_bsdf(lobe, lobe2, nlobes);
+    }
+}
+
 // TABLES: 0 = every table read from global memory, 1 = all of them in LDS (scenes of at most 64 slots), 2 = materials, textures and
 // lights in LDS, the per-slot tables in global memory.
 // FUSE (TABLES == 1 scenes whose tree also fits the LDS walk): the shadow ray of next-event estimation is traced here, out of an
@@ -804,130 +940,10 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
             F3 T = f3(q.tr[i], q.tg[i], q.tb[i]);
             id = q.id[i];
             uint32_t state = q.state[i];
-            int depth = state & 0xFFFF;
-            int slot = hb.slot[i];
-            const DevMaterial &m = sc.materials[sc.slot_material[slot]];
-            SurfacePoint sp;
-            surface_point(sc, slot, o, d, hb.t[i], hb.b0[i], hb.b1[i], hb.b2[i], material_needs_uv<MAT>(sc, m), sp);
-            uint32_t pixel = id / (uint32_t)rp.spb, sample = (uint32_t)rp.sample0 + id % (uint32_t)rp.spb;
-            uint32_t a0 = pixel, a1 = sample, a2 = (uint32_t)depth, a3 = 0;   // {light pick, uLight.x, uLight.y, roulette}
-            philox4x32(a0, a1, a2, a3, rp.k0, rp.k1);
-            // ---- BSDF sampling, integrator.cpp:265-279 + BSDF::Sample_f reflection.cpp:173-217 (as a lambda: the matte kernel runs it
-            // a second time, specialised for a mirror lobe, when mirror paths ride in its list)
-            auto sample_bsdf = [&](const Lobe &lobe, const Lobe &lobe2, const int nlobes) {
-                uint32_t b0 = pixel, b1 = sample, b2 = (uint32_t)depth, b3 = 1;   // {bsdf.x, bsdf.y, -, -}
-                philox4x32(b0, b1, b2, b3, rp.k0, rp.k1);
-                // BSDF::Sample_f: component min(floor(u0 * n), n - 1), u0 remapped (reflection.cpp:176-190)
-                float ub = u32_to_unit(b0), u1 = u32_to_unit(b1);
-                int comp = nlobes == 1 ? 0 : min((int)floorf(ub * nlobes), nlobes - 1);
-                float u0 = fminf(ub * nlobes - comp, RT_ONE_MINUS_EPS);
-                Lobe chosen = lobe, other = lobe2;
-                if (nlobes == 2 && comp == 1) { chosen = lobe2; other = lobe; }
-                F3 woW = -d;
-                F3 wol = to_local(sp, woW), wil; float pdf = 0.f;
-                F3 f = f3(0.f, 0.f, 0.f);
-                if (wol.z != 0) {
-                    f = lobe_sample(chosen, wol, u0, u1, wil, pdf);
-                    if (pdf == 0) f = f3(0.f, 0.f, 0.f);
-                    else {
-                        F3 wiW = to_world(sp, wil);
-                        if (nlobes == 2) { pdf += lobe_pdf(other, wol, wil); pdf /= nlobes; }      // reflection.cpp:199-204
-                        if (!lobe_is_specular(chosen.kind)) {
-                            bool reflect = dot3(wiW, sp.n) * dot3(woW, sp.n) > 0;
-                            f = f3(0.f, 0.f, 0.f);
-                            if (reflect) {
-                                f = lobe_f(lobe, wol, wil);
-                                if (nlobes == 2) f = f + lobe_f(lobe2, wol, wil);
-                            }
-                        }
-                        if (!black3(f) && pdf != 0.f) {
-                            float ad = fabsf(dot3(wiW, sp.n));
-                            F3 beta = cdiv(f3(f.x * ad, f.y * ad, f.z * ad), pdf);
-                            bool alive = true;
-                            if (depth > 3) {
-                                float qq = fmaxf(.05f, 1 - maxcomp3(beta));
-                                if (u32_to_unit(a3) < qq) alive = false;
-                                beta = cdiv(beta, 1 - qq);
-                            }
-                            if (alive) {
-                                has_next = true;
-                                no = offset_ray_origin(sp.p, sp.n, wiW); nd = wiW; nT = T * beta;
-                                nstate = (uint32_t)(depth + 1) | (lobe_is_specular(chosen.kind) ? (1u << 16) : 0u);
-                            }
-                        }
-                    }
-                }
-            };
-            // Mirror paths that k_extend binned with the matte ones (RenderParams::merge_mirror): MirrorMaterial has one specular lobe,
-            // so there is no next-event estimation and the whole shading is one reflection (material.cpp:12-20, reflection.cpp:62-68).
-            // Their own launch read its short index list with sparse gathers and cost 4 % of a Cornell frame.
-            if (MAT == RT_MAT_MATTE && rp.merge_mirror && m.kind == RT_MAT_MIRROR) {
-                Lobe lm, none; none.kind = 0;
-                build_lobe<RT_MAT_MIRROR>(sc, m, sp.u, sp.v, lm);
-                if (lm.kind != 0) sample_bsdf(lm, none, 1);
-            } else {
-                Lobe lobe, lobe2;       // lobe2: only PlasticMaterial has a second lobe (BSDF::Add order: Lambert, then microfacet)
-                build_lobe<MAT>(sc, m, sp.u, sp.v, lobe);
-                lobe2.kind = 0;
-                if (MAT == RT_MAT_PLASTIC) {
-                    build_plastic_gloss(sc, m, sp.u, sp.v, lobe2);
-                    if (lobe.kind == 0) { lobe = lobe2; lobe2.kind = 0; }
-                }
-                const int nlobes = (MAT == RT_MAT_PLASTIC && lobe2.kind != 0) ? 2 : 1;
-                // ---- next-event estimation: UniformSampleOneLight + EstimateDirect, integrator.cpp:53-102,259-264
-                if (lobe.kind != 0 && !lobe_is_specular(lobe.kind) && sc.n_lights > 0) {
-                    int nL = sc.n_lights;
-                    int ln = min((int)(u32_to_unit(a0) * nL), nL - 1);
-                    float selPdf = 1.f / nL;
-                    const DevLight &L = sc.lights[ln];
-                    float u0 = u32_to_unit(a1), u1 = u32_to_unit(a2);
-                    F3 p0 = f3(L.p0[0], L.p0[1], L.p0[2]), p1 = f3(L.p1[0], L.p1[1], L.p1[2]), p2 = f3(L.p2[0], L.p2[1], L.p2[2]);
-                    float su0 = sqrtf(u0);
-                    float lb0 = 1 - su0, lb1 = u1 * su0;                       // UniformSampleTriangle, sampling.cpp:108-111
-                    F3 lp = (lb0 * p0 + lb1 * p1) + (1 - lb0 - lb1) * p2;      // Triangle::Sample, triangle.cpp:229-248
-                    F3 lnrm = f3(L.n[0], L.n[1], L.n[2]);
-                    if (L.has_n) {
-                        float w2 = 1 - lb0 - lb1;
-                        F3 ns = (lb0 * f3(L.vn[0], L.vn[1], L.vn[2]) + lb1 * f3(L.vn[3], L.vn[4], L.vn[5])) + w2 * f3(L.vn[6], L.vn[7], L.vn[8]);
-                        if (dot3(lnrm, ns) < 0.f) lnrm = -lnrm;
-                    }
-                    float pdf = 1 / L.area;
-                    F3 wi = lp - sp.p;                                          // Shape::Sample(ref,u,pdf), shape.cpp:20-31
-                    if (lensq(wi) == 0) pdf = 0;
-                    else {
-                        wi = normalize3(wi);
-                        pdf *= lensq(sp.p - lp) / fabsf(dot3(lnrm, -wi));
-                        if (isinf(pdf)) pdf = 0.f;
-                    }
-                    F3 Li = f3(0.f, 0.f, 0.f);                                  // DiffuseAreaLight::Sample_Li, light.cpp:43-54
-                    if (pdf == 0 || lensq(lp - sp.p) == 0) pdf = 0;
-                    else {
-                        wi = normalize3(lp - sp.p);
-                        if (L.two_sided || dot3(lnrm, -wi) > 0) Li = f3(L.Le[0], L.Le[1], L.Le[2]);
-                    }
-                    if (pdf > 0 && !black3(Li)) {
-                        // BSDF::f(wo, wi, ALL & ~SPECULAR) * AbsDot(wi, ns), reflection.cpp:140-152
-                        F3 wol = to_local(sp, sp.wo), wil = to_local(sp, wi);
-                        F3 f = f3(0.f, 0.f, 0.f);
-                        if (wol.z != 0) {
-                            bool reflect = dot3(wi, sp.n) * dot3(sp.wo, sp.n) > 0;
-                            if (reflect) {
-                                f = lobe_f(lobe, wol, wil);
-                                if (nlobes == 2) f = f + lobe_f(lobe2, wol, wil);
-                            }
-                        }
-                        float ad = fabsf(dot3(wi, sp.n));
-                        f = f3(f.x * ad, f.y * ad, f.z * ad);
-                        if (!black3(f)) {
-                            F3 origin = offset_ray_origin(sp.p, sp.n, lp - sp.p);     // Interaction::SpawnRayTo, interaction.h:27-32
-                            F3 target = offset_ray_origin(lp, lnrm, origin - lp);
-                            F3 Ld = cdiv(cdiv(f * Li, pdf), selPdf);
-                            has_shadow = true; so = origin; sd = target - origin; sc3 = T * Ld;
-                        }
-                    }
-                }
-                if (lobe.kind != 0) sample_bsdf(lobe, lobe2, nlobes);
-            }
+            ShadeOut out;
+            shade_path<MAT>(sc, rp, o, d, T, id, state, hb.slot[i], hb.t[i], hb.b0[i], hb.b1[i], hb.b2[i], out);
+            has_shadow = out.has_shadow; has_next = out.has_next; nstate = out.nstate;
+            so = out.so; sd = out.sd; sc3 = out.sc3; no = out.no; nd = out.nd; nT = out.nT;
         }
         if (FUSE) {            // bvh.cpp:284-320 on the spot; tMax = 1 - ShadowEpsilon (interaction.h:27-32)
             n_shadow_rays += (uint32_t)__popcll(__ballot(has_shadow));
