@@ -123,6 +123,18 @@ __device__ __forceinline__ void block_share(uint32_t total, uint32_t &lo, uint32
     lo = (uint32_t)(l < total ? l : total);
     hi = (uint32_t)((l + share) < total ? (l + share) : total);
 }
+// The waves of the grid take the chunks of RT_WAVE consecutive queue positions round robin (wave w: chunks w, w + W, ...; see
+// block_share for why).  WaveChunks maps a wave's k-th chunk to its first queue position.
+struct WaveChunks {
+    uint32_t n_waves, gwave, n_mine, total;
+    __device__ __forceinline__ WaveChunks(uint32_t total_) : total(total_) {
+        n_waves = gridDim.x * (RT_BLOCK / RT_WAVE); gwave = blockIdx.x * (RT_BLOCK / RT_WAVE) + threadIdx.x / RT_WAVE;
+        const uint32_t n_chunks = (total + RT_WAVE - 1) / RT_WAVE;
+        n_mine = gwave < n_chunks ? (n_chunks - gwave + n_waves - 1) / n_waves : 0;
+    }
+    __device__ __forceinline__ uint32_t first(uint32_t k) const { return (k * n_waves + gwave) * RT_WAVE; }
+};
+
 // Segment that holds concatenated index g (s_prefix[s] <= g < s_prefix[s+1]); g < total.
 __device__ __forceinline__ uint32_t segment_of(const uint32_t *s_prefix, uint32_t g) {
     uint32_t lo = 0, hi = gridDim.x;   // invariant: s_prefix[lo] <= g < s_prefix[hi]
@@ -976,6 +988,100 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
     if (FUSE && (threadIdx.x & (RT_WAVE - 1)) == 0 && n_shadow_rays) atomicAdd(&stats[bounce].n_shadow, n_shadow_rays);   // statistics only
 }
 
+// ------------------------------------------------------------------ finish --
+// The late bounces of a pass hold a fraction of a percent of its paths, but every bounce still costs two or three launches of
+// 10-60 us each (one chunk per wave: the whole latency chain of a kernel for almost no work).  k_finish takes the queue of one
+// bounce of a scene that lives in LDS and follows every path in it to its end inside one launch — closest hit, emission /
+// termination, shading, shadow ray, next ray — with the same device functions in the same order as the kernels it stands in
+// for, so the radiance of every path is the same to the last bit.  The host switches to it at the bounce where, going by the
+// survival fractions of an earlier pass over the same scene, no more than two chunks per wave are left (rt_render_device).
+__global__ __launch_bounds__(RT_BLOCK) void k_finish(DevScene sc_in, RenderParams rp, int bounce, PathQueue q, uint32_t segcap, float4 *lbuf, BounceCounts *counts,
+                                                      BounceStats *stats) {
+    __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE];
+    extern __shared__ float4 s_dyn[];
+    __shared__ float4 s_pairs[2 * RT_LDS_SCENE_NODES];
+    __shared__ int s_stack[2 * RT_FRAME_RING * RT_BLOCK];
+    DevScene sc = sc_in;
+    const int ns = sc_in.n_slots;                                  // the table layout of k_shade<.., TABLES = 1, ..>
+    float4 *t_slots = s_dyn, *t_frames = t_slots + 3 * ns;
+    DevTexture *t_tex = (DevTexture *)(t_frames + 3 * ns);
+    DevLight *t_lights = (DevLight *)(t_tex + sc_in.n_textures);
+    DevMaterial *t_mats = (DevMaterial *)(t_lights + sc_in.n_lights);
+    float *t_uv = (float *)(t_mats + sc_in.n_materials);
+    int *t_slot_mat = (int *)(t_uv + 6 * ns);
+    copy_words_to_lds(t_slots, sc_in.slots, 48 * ns); copy_words_to_lds(t_frames, sc_in.frames, 48 * ns);
+    copy_words_to_lds(t_uv, sc_in.slot_uv, 24 * ns); copy_words_to_lds(t_slot_mat, sc_in.slot_material, 4 * ns);
+    copy_words_to_lds(t_mats, sc_in.materials, (int)sizeof(DevMaterial) * sc_in.n_materials);
+    copy_words_to_lds(t_tex, sc_in.textures, (int)sizeof(DevTexture) * sc_in.n_textures);
+    copy_words_to_lds(t_lights, sc_in.lights, (int)sizeof(DevLight) * sc_in.n_lights);
+    sc.slots = t_slots; sc.frames = t_frames; sc.slot_uv = t_uv; sc.slot_material = t_slot_mat; sc.materials = t_mats; sc.textures = t_tex; sc.lights = t_lights;
+    stage_pairs_lds(sc_in, s_pairs);
+    PairStackT<RT_FRAME_RING, false> pst; pst.lds_i = &s_stack[threadIdx.x]; pst.lds_t = (float *)&s_stack[RT_FRAME_RING * RT_BLOCK + threadIdx.x]; pst.reset();
+    const uint32_t total = segment_prefix(counts[bounce].queue, s_prefix, s_wave);     // its barriers order the copies above before their use
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_queue = total;
+    const WaveChunks wc(total);
+    uint32_t seg = 0, n_closest = 0, n_shadow = 0;                 // rays beyond the first of each path, shadow rays (statistics)
+    for (uint32_t k = 0; k < wc.n_mine; ++k) {
+        const uint32_t g = wc.first(k) + lane_id();
+        if (g >= total) continue;
+        while (g >= s_prefix[seg + 1]) seg++;
+        const uint32_t i = seg * segcap + (g - s_prefix[seg]);
+        F3 o = f3(q.ox[i], q.oy[i], q.oz[i]), d = f3(q.dx[i], q.dy[i], q.dz[i]), T = f3(q.tr[i], q.tg[i], q.tb[i]);
+        const uint32_t id = q.id[i];
+        uint32_t state = q.state[i];
+        float4 Lr = lbuf[id];
+        for (bool first = true;; first = false) {
+            if (!first) n_closest++;
+            LaneTrav L = {};
+            trace_one<false, RT_LDS_SCENE_NODES / 2>(sc_in, s_pairs, t_slots, o, d, RT_INF, pst, L);
+            const bool found = L.found;
+            const int slot = found ? L.hitSlot : -1;
+            const int depth = state & 0xFFFF; const bool spec = (state >> 16) & 1;
+            // integrator.cpp:242-257, as in k_extend
+            F3 add = f3(0.f, 0.f, 0.f); bool terminal = false;
+            if (depth == 0 || spec || sc.n_lights == 0) {
+                if (found) {
+                    int li = sc_in.slot_light[slot];
+                    if (li >= 0) {
+                        const DevLight &Lt = sc.lights[li];
+                        float4 nf = sc.frames[3 * slot];
+                        if (Lt.two_sided || dot3(f3(nf.x, nf.y, nf.z), -d) > 0) add = f3(Lt.Le[0], Lt.Le[1], Lt.Le[2]);   // light.h:73-75
+                        if (!black3(add)) terminal = true;
+                    }
+                } else if (sc.n_lights == 0) {
+                    F3 ud = normalize3(d);
+                    double t = 0.5 * (ud.y + 1.0);
+                    float a = (float)(1.0 - t), b = (float)t;
+                    add = f3(1.0f * a + 0.5f * b, 1.0f * a + 0.7f * b, 1.0f * a + 1.0f * b);
+                }
+            }
+            if (!found || depth >= rp.max_depth) terminal = true;
+            if (!black3(add)) { Lr.x += T.x * add.x; Lr.y += T.y * add.y; Lr.z += T.z * add.z; }
+            if (terminal) break;
+            ShadeOut out;
+            switch (sc.materials[sc.slot_material[slot]].kind) {
+                case RT_MAT_MATTE: shade_path<RT_MAT_MATTE>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
+                case RT_MAT_MIRROR: shade_path<RT_MAT_MIRROR>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
+                case RT_MAT_GLASS: shade_path<RT_MAT_GLASS>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
+                case RT_MAT_METAL: shade_path<RT_MAT_METAL>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
+                case RT_MAT_PLASTIC: shade_path<RT_MAT_PLASTIC>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
+                default: shade_path<RT_MAT_METALROUGH>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
+            }
+            if (out.has_shadow) {                                   // bvh.cpp:284-320; tMax = 1 - ShadowEpsilon (interaction.h:27-32)
+                n_shadow++;
+                LaneTrav S = {};
+                trace_one<true, RT_LDS_SCENE_NODES / 2>(sc_in, s_pairs, t_slots, out.so, out.sd, 1.f - 0.0001f, pst, S);
+                if (!S.found) { Lr.x += out.sc3.x; Lr.y += out.sc3.y; Lr.z += out.sc3.z; }
+            }
+            if (!out.has_next) break;
+            o = out.no; d = out.nd; T = out.nT; state = out.nstate;
+        }
+        lbuf[id] = Lr;
+    }
+    if (n_closest) atomicAdd(&stats[bounce + 1].n_queue, n_closest);      // statistics only
+    if (n_shadow) atomicAdd(&stats[bounce].n_shadow, n_shadow);
+}
+
 // ------------------------------------------------------------------ shadow --
 template <bool LDS_SCENE>
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, ShadowQueue sq, uint32_t segcap, float4 *lbuf, BounceCounts *counts,
@@ -1037,18 +1143,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, Sh
 enum { RT_WALK_QUADS = 1, RT_WALK_PAIRS = 2 };
 
 struct RayArrays { const float *ox, *oy, *oz, *dx, *dy, *dz; };
-
-// The waves of the grid take the chunks of RT_WAVE consecutive queue positions round robin (wave w: chunks w, w + W, ...; see
-// block_share for why).  WaveChunks maps a wave's k-th chunk to its first queue position.
-struct WaveChunks {
-    uint32_t n_waves, gwave, n_mine, total;
-    __device__ __forceinline__ WaveChunks(uint32_t total_) : total(total_) {
-        n_waves = gridDim.x * (RT_BLOCK / RT_WAVE); gwave = blockIdx.x * (RT_BLOCK / RT_WAVE) + threadIdx.x / RT_WAVE;
-        const uint32_t n_chunks = (total + RT_WAVE - 1) / RT_WAVE;
-        n_mine = gwave < n_chunks ? (n_chunks - gwave + n_waves - 1) / n_waves : 0;
-    }
-    __device__ __forceinline__ uint32_t first(uint32_t k) const { return (k * n_waves + gwave) * RT_WAVE; }
-};
 
 // Traverse this wave's chunks of the `total` concatenated positions of a segmented queue; sink(i, L) receives each finished ray
 // (i = its position in the queue arrays).  recs = pair or quad records (LDS or global), slots = leaf slots.
@@ -1295,6 +1389,7 @@ struct rt_scene {
     bool classes[RT_NUM_CLASSES] = {false, false, false, false, false, false};
     DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_spill, d_pairs, d_quads;
     int interior_depth = 0;
+    std::vector<float> survival;     // fraction of a pass's paths still alive at each bounce, from the last pass that ran every bounce (k_finish)
     std::vector<DevBuf *> d_texels;
     // render workspace
     DevBuf d_q[2], d_hits, d_cls, d_shadow, d_lbuf, d_counters, d_sum, d_trace_io, d_work;
@@ -1846,13 +1941,26 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     // (only while five blocks of the fused kernel still share a CU's 160 KB of LDS: 25.6 KB static + the scene's tables <= 32 KB)
     const bool fuse_shadow = lds_scene && round_pairs && !frame_old && shade_tables_in_lds(this_->dev) && shade_lds_bytes(this_->dev) <= 6400 &&
                              env_int("RT_AMD_FUSE_SHADOW", 1) != 0;
+    // the late, near-empty bounces of LDS scenes in one launch (k_finish)
+    const bool use_finish = fuse_shadow && env_int("RT_AMD_FINISH", 1) != 0;
+    const int finish_chunks = env_int("RT_AMD_FINISH_CHUNKS", 2);
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
         int cur = std::min(spb, o->sample_end - s0);
         rp.spb = cur; rp.sample0 = s0; rp.n_paths = (uint32_t)(npix * (size_t)cur);
         HIP_OK(hipMemsetAsync(bstats, 0, stats_bytes, ctx->stream));
         hipLaunchKernelGGL(k_raygen, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, rp, q[0], useg, lbuf, counts);
         int cq = 0;
+        // k_finish takes over at the first bounce expected to hold no more than two chunks of 64 paths per wave of the grid
+        int finish_at = 1 << 30;
+        if (use_finish)
+            for (size_t b = 4; b < this_->survival.size(); ++b)
+                if ((double)this_->survival[b] * rp.n_paths <= (double)finish_chunks * RT_WAVE * (RT_BLOCK / RT_WAVE) * nseg) { finish_at = (int)b; break; }
         for (int b = 0; b <= o->max_depth; ++b) {
+            if (b >= finish_at) {
+                hipLaunchKernelGGL(k_finish, dim3(nseg), dim3(RT_BLOCK), shade_lds_bytes(this_->dev), ctx->stream, this_->dev, rp, b, q[cq], useg, lbuf, counts,
+                                   bstats);
+                break;
+            }
             if (frame_old || b < round_bounces) {
                 if (lds_scene && round_pairs && b >= carry_from)
                     hipLaunchKernelGGL(k_extend_carry, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
@@ -1906,6 +2014,10 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
         HIP_OK(hipStreamSynchronize(ctx->stream));
         st.samples += rp.n_paths;
         for (size_t b = 0; b < n_bounce; ++b) { st.rays_closest += hs[b].n_queue; st.rays_shadow += hs[b].n_shadow; if (hs[b].n_queue) st.iterations++; }
+        if (use_finish && finish_at == 1 << 30 && rp.n_paths >= 4096) {       // a pass through every bounce: note how fast the paths die out
+            this_->survival.assign((size_t)o->max_depth + 1, 0.f);
+            for (int b = 0; b <= o->max_depth; ++b) this_->survival[b] = (float)((double)hs[b].n_queue / rp.n_paths);
+        }
     }
     HIP_OK(hipEventRecord(e1, ctx->stream));
     HIP_OK(hipEventSynchronize(e1));
