@@ -993,7 +993,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
 // 10-60 us each (one chunk per wave: the whole latency chain of a kernel for almost no work).  k_finish takes the queue of one
 // bounce of a scene that lives in LDS and follows every path in it to its end inside one launch — closest hit, emission /
 // termination, shading, shadow ray, next ray — with the same device functions in the same order as the kernels it stands in
-// for, so the radiance of every path is the same to the last bit.  The host switches to it at the bounce where, going by the
+// for, so the radiance of every path is the same to the last bit.  A lane whose path has ended takes the next one at once.  The host switches to it at the bounce where, going by the
 // survival fractions of an earlier pass over the same scene, no more than two chunks per wave are left (rt_render_device).
 __global__ __launch_bounds__(RT_BLOCK) void k_finish(DevScene sc_in, RenderParams rp, int bounce, PathQueue q, uint32_t segcap, float4 *lbuf, BounceCounts *counts,
                                                       BounceStats *stats) {
@@ -1021,17 +1021,40 @@ __global__ __launch_bounds__(RT_BLOCK) void k_finish(DevScene sc_in, RenderParam
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_queue = total;
     const WaveChunks wc(total);
     uint32_t seg = 0, n_closest = 0, n_shadow = 0;                 // rays beyond the first of each path, shadow rays (statistics)
-    for (uint32_t k = 0; k < wc.n_mine; ++k) {
-        const uint32_t g = wc.first(k) + lane_id();
-        if (g >= total) continue;
-        while (g >= s_prefix[seg + 1]) seg++;
-        const uint32_t i = seg * segcap + (g - s_prefix[seg]);
-        F3 o = f3(q.ox[i], q.oy[i], q.oz[i]), d = f3(q.dx[i], q.dy[i], q.dz[i]), T = f3(q.tr[i], q.tg[i], q.tb[i]);
-        const uint32_t id = q.id[i];
-        uint32_t state = q.state[i];
-        float4 Lr = lbuf[id];
-        for (bool first = true;; first = false) {
+    // One iteration = one bounce for every lane that holds a path; a lane whose path has ended takes the next one of the wave's
+    // chunks at the top of the next iteration, so the wave does not wait for the longest of 64 paths.
+    uint32_t w_chunk = 0, c_next = RT_WAVE, c_first = 0, c_count = 0;   // chunks begun; read cursor / first position / size of the current one
+    bool busy = false, first = true;
+    F3 o = f3(0, 0, 0), d = f3(0, 0, 1), T = f3(0, 0, 0);
+    uint32_t id = 0, state = 0;
+    float4 Lr = make_float4(0.f, 0.f, 0.f, 0.f);
+    while (true) {
+        // ---- idle lanes take paths from the current chunk, then from the next ones
+        uint64_t im = __ballot(!busy);
+        while (im != 0) {
+            if (c_next >= c_count) {
+                if (w_chunk >= wc.n_mine) break;
+                c_first = wc.first(w_chunk++); c_next = 0; c_count = total - c_first < RT_WAVE ? total - c_first : RT_WAVE;
+            }
+            const uint32_t nidle = (uint32_t)__popcll(im), left = c_count - c_next, take = nidle < left ? nidle : left;
+            const uint32_t rank = prefix_in_mask(im);
+            if (!busy && rank < take) {
+                const uint32_t g = c_first + c_next + rank;
+                while (g >= s_prefix[seg + 1]) seg++;
+                const uint32_t i = seg * segcap + (g - s_prefix[seg]);
+                o = f3(q.ox[i], q.oy[i], q.oz[i]); d = f3(q.dx[i], q.dy[i], q.dz[i]); T = f3(q.tr[i], q.tg[i], q.tb[i]);
+                id = q.id[i]; state = q.state[i];
+                Lr = lbuf[id];
+                busy = true; first = true;
+            }
+            c_next += take;
+            im = __ballot(!busy);
+        }
+        if (__ballot(busy) == 0) break;
+        if (busy) {
             if (!first) n_closest++;
+            first = false;
+            bool ended = true;
             LaneTrav L = {};
             trace_one<false, RT_LDS_SCENE_NODES / 2>(sc_in, s_pairs, t_slots, o, d, RT_INF, pst, L);
             const bool found = L.found;
@@ -1057,26 +1080,26 @@ __global__ __launch_bounds__(RT_BLOCK) void k_finish(DevScene sc_in, RenderParam
             }
             if (!found || depth >= rp.max_depth) terminal = true;
             if (!black3(add)) { Lr.x += T.x * add.x; Lr.y += T.y * add.y; Lr.z += T.z * add.z; }
-            if (terminal) break;
-            ShadeOut out;
-            switch (sc.materials[sc.slot_material[slot]].kind) {
-                case RT_MAT_MATTE: shade_path<RT_MAT_MATTE>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
-                case RT_MAT_MIRROR: shade_path<RT_MAT_MIRROR>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
-                case RT_MAT_GLASS: shade_path<RT_MAT_GLASS>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
-                case RT_MAT_METAL: shade_path<RT_MAT_METAL>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
-                case RT_MAT_PLASTIC: shade_path<RT_MAT_PLASTIC>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
-                default: shade_path<RT_MAT_METALROUGH>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
+            if (!terminal) {
+                ShadeOut out;
+                switch (sc.materials[sc.slot_material[slot]].kind) {
+                    case RT_MAT_MATTE: shade_path<RT_MAT_MATTE>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
+                    case RT_MAT_MIRROR: shade_path<RT_MAT_MIRROR>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
+                    case RT_MAT_GLASS: shade_path<RT_MAT_GLASS>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
+                    case RT_MAT_METAL: shade_path<RT_MAT_METAL>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
+                    case RT_MAT_PLASTIC: shade_path<RT_MAT_PLASTIC>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
+                    default: shade_path<RT_MAT_METALROUGH>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
+                }
+                if (out.has_shadow) {                               // bvh.cpp:284-320; tMax = 1 - ShadowEpsilon (interaction.h:27-32)
+                    n_shadow++;
+                    LaneTrav S = {};
+                    trace_one<true, RT_LDS_SCENE_NODES / 2>(sc_in, s_pairs, t_slots, out.so, out.sd, 1.f - 0.0001f, pst, S);
+                    if (!S.found) { Lr.x += out.sc3.x; Lr.y += out.sc3.y; Lr.z += out.sc3.z; }
+                }
+                if (out.has_next) { o = out.no; d = out.nd; T = out.nT; state = out.nstate; ended = false; }
             }
-            if (out.has_shadow) {                                   // bvh.cpp:284-320; tMax = 1 - ShadowEpsilon (interaction.h:27-32)
-                n_shadow++;
-                LaneTrav S = {};
-                trace_one<true, RT_LDS_SCENE_NODES / 2>(sc_in, s_pairs, t_slots, out.so, out.sd, 1.f - 0.0001f, pst, S);
-                if (!S.found) { Lr.x += out.sc3.x; Lr.y += out.sc3.y; Lr.z += out.sc3.z; }
-            }
-            if (!out.has_next) break;
-            o = out.no; d = out.nd; T = out.nT; state = out.nstate;
+            if (ended) { lbuf[id] = Lr; busy = false; }
         }
-        lbuf[id] = Lr;
     }
     if (n_closest) atomicAdd(&stats[bounce + 1].n_queue, n_closest);      // statistics only
     if (n_shadow) atomicAdd(&stats[bounce].n_shadow, n_shadow);
