@@ -1976,7 +1976,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
         // k_finish takes over at the first bounce expected to hold no more than two chunks of 64 paths per wave of the grid
         int finish_at = 1 << 30;
         if (use_finish)
-            for (size_t b = 4; b < this_->survival.size(); ++b)
+            for (size_t b = (size_t)env_int("RT_AMD_FINISH_MIN_BOUNCE", 4); b < this_->survival.size(); ++b)
                 if ((double)this_->survival[b] * rp.n_paths <= (double)finish_chunks * RT_WAVE * (RT_BLOCK / RT_WAVE) * nseg) { finish_at = (int)b; break; }
         for (int b = 0; b <= o->max_depth; ++b) {
             if (b >= finish_at) {
