@@ -251,7 +251,7 @@ def main():
             "dtype": "f32", "data": "synthetic (the reference's Cornellbox() scene, built by the host surface)",
             "config": {"workload": "Cornell box 800x800, 1024 spp (32x32 strata), maxDepth 50, samples split across ranks, one RCCL reduce",
                        "parallelism": "spp-split x%d" % world},
-            "mrays_per_s": round((stats.rays_closest + stats.rays_shadow) * world * args.steps / dt / 1e6 / args.steps, 1) if stats else None,
+            "mrays_per_s": round((stats.rays_closest + stats.rays_shadow) * world * args.steps / dt / 1e6, 1) if stats else None,
             "image_mean_rgb": [round(float(v), 5) for v in img.mean(axis=(0, 1))],
         }
         if not args.no_roofline:
