@@ -287,7 +287,7 @@ def test_headline_frame_against_reference_and_shipped_image(device_scene, host_s
     assert np.all(np.abs(ratio - 1) < 0.03), ratio
 
 
-@pytest.mark.parametrize("name,w", [("cornell", 200), ("helmet", 160), ("spheres2", 160)])
+@pytest.mark.parametrize("name,w", [("cornell", 200), ("cornell_plastic", 120), ("helmet", 160), ("spheres2", 160)])
 def test_frame_walks_give_identical_images(name, w, device_scene, host_scene, monkeypatch):
     """The frame kernels have three walks (round-based over pair/quad records, persistent lanes, round-based over plain
     nodes) and several ways of dividing and fusing the work.  Traversal is bit-exact in all of them and every sample is a pure
