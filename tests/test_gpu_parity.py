@@ -240,6 +240,21 @@ def test_render_odd_image_shapes(name, device_scene, oracle_scene, host_scene):
         assert _rel_close(img, ref, 2e-3).mean() > 0.99, (w, h)
 
 
+@pytest.mark.parametrize("name,w,h", [("helmet", 1440, 1440), ("spheres2", 1440, 810)])
+def test_full_resolution_frames_match_oracle(name, w, h, device_scene, oracle_scene, host_scene):
+    """The large configurations at their own resolution (one sample per pixel keeps the oracle to seconds): ray counts and
+    per-pixel agreement as in the small renders."""
+    cam = host_scene(name).camera(w, h)
+    opts = ra.make_opts(1, 1)
+    img, st = device_scene(name).render(cam, opts)
+    ref, cnt = oracle_scene(name).render(cam, opts, mode=1, threads=16)
+    assert st.samples == w * h == cnt["samples"]
+    assert abs(int(st.rays_closest) - int(cnt["closest"])) <= 1e-4 * cnt["closest"] + 4
+    assert abs(int(st.rays_shadow) - int(cnt["shadow"])) <= 1e-4 * cnt["shadow"] + 4
+    assert _rel_close(img, ref, 2e-3).mean() > 0.995
+    assert np.all(np.abs(img.mean(axis=(0, 1)) / ref.mean(axis=(0, 1)) - 1) < 2e-3)
+
+
 def test_render_properties_at_full_size(device_scene, host_scene):
     """Size-independent properties on the headline configuration's resolution (Cornell 800x800):
     sample ranges add up (the multi-GPU split), passes of different sizes give the same image, runs are reproducible."""
