@@ -991,32 +991,49 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
 // ------------------------------------------------------------------ finish --
 // The late bounces of a pass hold a fraction of a percent of its paths, but every bounce still costs two or three launches of
 // 10-60 us each (one chunk per wave: the whole latency chain of a kernel for almost no work).  k_finish takes the queue of one
-// bounce of a scene that lives in LDS and follows every path in it to its end inside one launch — closest hit, emission /
+// bounce and follows every path in it to its end inside one launch — closest hit, emission /
 // termination, shading, shadow ray, next ray — with the same device functions in the same order as the kernels it stands in
 // for, so the radiance of every path is the same to the last bit.  A lane whose path has ended takes the next one at once.  The host switches to it at the bounce where, going by the
 // survival fractions of an earlier pass over the same scene, no more than two chunks per wave are left (rt_render_device).
+template <bool LDS_SCENE>
 __global__ __launch_bounds__(RT_BLOCK) void k_finish(DevScene sc_in, RenderParams rp, int bounce, PathQueue q, uint32_t segcap, float4 *lbuf, BounceCounts *counts,
-                                                      BounceStats *stats) {
+                                                      BounceStats *stats, int *spill) {
     __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE];
     extern __shared__ float4 s_dyn[];
-    __shared__ float4 s_pairs[2 * RT_LDS_SCENE_NODES];
+    __shared__ float4 s_pairs[LDS_SCENE ? 2 * RT_LDS_SCENE_NODES : 1];
     __shared__ int s_stack[2 * RT_FRAME_RING * RT_BLOCK];
     DevScene sc = sc_in;
-    const int ns = sc_in.n_slots;                                  // the table layout of k_shade<.., TABLES = 1, ..>
-    float4 *t_slots = s_dyn, *t_frames = t_slots + 3 * ns;
-    DevTexture *t_tex = (DevTexture *)(t_frames + 3 * ns);
-    DevLight *t_lights = (DevLight *)(t_tex + sc_in.n_textures);
-    DevMaterial *t_mats = (DevMaterial *)(t_lights + sc_in.n_lights);
-    float *t_uv = (float *)(t_mats + sc_in.n_materials);
-    int *t_slot_mat = (int *)(t_uv + 6 * ns);
-    copy_words_to_lds(t_slots, sc_in.slots, 48 * ns); copy_words_to_lds(t_frames, sc_in.frames, 48 * ns);
-    copy_words_to_lds(t_uv, sc_in.slot_uv, 24 * ns); copy_words_to_lds(t_slot_mat, sc_in.slot_material, 4 * ns);
-    copy_words_to_lds(t_mats, sc_in.materials, (int)sizeof(DevMaterial) * sc_in.n_materials);
-    copy_words_to_lds(t_tex, sc_in.textures, (int)sizeof(DevTexture) * sc_in.n_textures);
-    copy_words_to_lds(t_lights, sc_in.lights, (int)sizeof(DevLight) * sc_in.n_lights);
-    sc.slots = t_slots; sc.frames = t_frames; sc.slot_uv = t_uv; sc.slot_material = t_slot_mat; sc.materials = t_mats; sc.textures = t_tex; sc.lights = t_lights;
-    stage_pairs_lds(sc_in, s_pairs);
+    const float4 *t_slots = sc_in.slots;
+    if (LDS_SCENE) {
+        const int ns = sc_in.n_slots;                              // the table layout of k_shade<.., TABLES = 1, ..>
+        float4 *l_slots = s_dyn, *t_frames = l_slots + 3 * ns;
+        DevTexture *t_tex = (DevTexture *)(t_frames + 3 * ns);
+        DevLight *t_lights = (DevLight *)(t_tex + sc_in.n_textures);
+        DevMaterial *t_mats = (DevMaterial *)(t_lights + sc_in.n_lights);
+        float *t_uv = (float *)(t_mats + sc_in.n_materials);
+        int *t_slot_mat = (int *)(t_uv + 6 * ns);
+        copy_words_to_lds(l_slots, sc_in.slots, 48 * ns); copy_words_to_lds(t_frames, sc_in.frames, 48 * ns);
+        copy_words_to_lds(t_uv, sc_in.slot_uv, 24 * ns); copy_words_to_lds(t_slot_mat, sc_in.slot_material, 4 * ns);
+        copy_words_to_lds(t_mats, sc_in.materials, (int)sizeof(DevMaterial) * sc_in.n_materials);
+        copy_words_to_lds(t_tex, sc_in.textures, (int)sizeof(DevTexture) * sc_in.n_textures);
+        copy_words_to_lds(t_lights, sc_in.lights, (int)sizeof(DevLight) * sc_in.n_lights);
+        sc.slots = l_slots; sc.frames = t_frames; sc.slot_uv = t_uv; sc.slot_material = t_slot_mat; sc.materials = t_mats; sc.textures = t_tex; sc.lights = t_lights;
+        t_slots = l_slots;
+        stage_pairs_lds(sc_in, s_pairs);
+    }
+    // LDS scenes: pair records in LDS, eight stack levels are enough; otherwise quad records in global memory and a stack that spills
     PairStackT<RT_FRAME_RING, false> pst; pst.lds_i = &s_stack[threadIdx.x]; pst.lds_t = (float *)&s_stack[RT_FRAME_RING * RT_BLOCK + threadIdx.x]; pst.reset();
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    PairStackT<RT_FRAME_RING, true> gst; gst.lds_i = pst.lds_i; gst.lds_t = pst.lds_t; gst.cap = sc_in.quad_stack_cap;
+    gst.spill_i = spill + gtid; gst.spill_t = (float *)(spill + (size_t)gst.cap * nthreads) + gtid; gst.spill_stride = nthreads; gst.reset();
+    auto trace_closest = [&](F3 o, F3 d, LaneTrav &L) {
+        if (LDS_SCENE) trace_one<false, RT_LDS_SCENE_NODES / 2>(sc_in, s_pairs, t_slots, o, d, RT_INF, pst, L);
+        else trace_one<false, 1, true>(sc_in, sc_in.quads, sc_in.slots, o, d, RT_INF, gst, L);
+    };
+    auto trace_shadow = [&](F3 o, F3 d, LaneTrav &L) {            // tMax = 1 - ShadowEpsilon (interaction.h:27-32)
+        if (LDS_SCENE) trace_one<true, RT_LDS_SCENE_NODES / 2>(sc_in, s_pairs, t_slots, o, d, 1.f - 0.0001f, pst, L);
+        else trace_one<true, 1, true>(sc_in, sc_in.quads, sc_in.slots, o, d, 1.f - 0.0001f, gst, L);
+    };
     const uint32_t total = segment_prefix(counts[bounce].queue, s_prefix, s_wave);     // its barriers order the copies above before their use
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_queue = total;
     const WaveChunks wc(total);
@@ -1056,7 +1073,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_finish(DevScene sc_in, RenderParam
             first = false;
             bool ended = true;
             LaneTrav L = {};
-            trace_one<false, RT_LDS_SCENE_NODES / 2>(sc_in, s_pairs, t_slots, o, d, RT_INF, pst, L);
+            trace_closest(o, d, L);
             const bool found = L.found;
             const int slot = found ? L.hitSlot : -1;
             const int depth = state & 0xFFFF; const bool spec = (state >> 16) & 1;
@@ -1093,7 +1110,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_finish(DevScene sc_in, RenderParam
                 if (out.has_shadow) {                               // bvh.cpp:284-320; tMax = 1 - ShadowEpsilon (interaction.h:27-32)
                     n_shadow++;
                     LaneTrav S = {};
-                    trace_one<true, RT_LDS_SCENE_NODES / 2>(sc_in, s_pairs, t_slots, out.so, out.sd, 1.f - 0.0001f, pst, S);
+                    trace_shadow(out.so, out.sd, S);
                     if (!S.found) { Lr.x += out.sc3.x; Lr.y += out.sc3.y; Lr.z += out.sc3.z; }
                 }
                 if (out.has_next) { o = out.no; d = out.nd; T = out.nT; state = out.nstate; ended = false; }
@@ -1965,7 +1982,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     const bool fuse_shadow = lds_scene && round_pairs && !frame_old && shade_tables_in_lds(this_->dev) && shade_lds_bytes(this_->dev) <= 6400 &&
                              env_int("RT_AMD_FUSE_SHADOW", 1) != 0;
     // the late, near-empty bounces of LDS scenes in one launch (k_finish)
-    const bool use_finish = fuse_shadow && env_int("RT_AMD_FINISH", 1) != 0;
+    const bool use_finish = (fuse_shadow || (!lds_scene && round_quads && !frame_old)) && env_int("RT_AMD_FINISH", 1) != 0;
     const int finish_chunks = env_int("RT_AMD_FINISH_CHUNKS", 2);
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
         int cur = std::min(spb, o->sample_end - s0);
@@ -1980,8 +1997,12 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                 if ((double)this_->survival[b] * rp.n_paths <= (double)finish_chunks * RT_WAVE * (RT_BLOCK / RT_WAVE) * nseg) { finish_at = (int)b; break; }
         for (int b = 0; b <= o->max_depth; ++b) {
             if (b >= finish_at) {
-                hipLaunchKernelGGL(k_finish, dim3(nseg), dim3(RT_BLOCK), shade_lds_bytes(this_->dev), ctx->stream, this_->dev, rp, b, q[cq], useg, lbuf, counts,
-                                   bstats);
+                if (lds_scene)
+                    hipLaunchKernelGGL(k_finish<true>, dim3(nseg), dim3(RT_BLOCK), shade_lds_bytes(this_->dev), ctx->stream, this_->dev, rp, b, q[cq], useg, lbuf,
+                                       counts, bstats, (int *)this_->d_spill.p);
+                else
+                    hipLaunchKernelGGL(k_finish<false>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], useg, lbuf, counts, bstats,
+                                       (int *)this_->d_spill.p);
                 break;
             }
             if (frame_old || b < round_bounces) {
