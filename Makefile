@@ -21,12 +21,13 @@ oracle:
 ref:
 	$(MAKE) -C oracle ref
 
-$(LIBDIR)/librt_amd.so: $(CSRC)/rt_kernels.hip $(CSRC)/rt_device.h $(CSRC)/rt_host_side.cpp include/rt_amd.h
+# every header of csrc/ is a prerequisite: the traversal code lives in headers that rt_kernels.hip includes
+$(LIBDIR)/librt_amd.so: $(CSRC)/rt_kernels.hip $(wildcard $(CSRC)/*.h) $(CSRC)/rt_host_side.cpp include/rt_amd.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/rt_kernels.hip -x hip $(CSRC)/rt_host_side.cpp
 
-$(LIBDIR)/librt_host.so: $(HOST)/rt_host.cpp $(HOST)/scenes.cpp $(HOST)/jpeg_decode.cpp $(HOST)/rt_host.h include/rt_amd.h $(LIBDIR)/librt_amd.so
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST)/rt_host.cpp $(HOST)/scenes.cpp $(HOST)/jpeg_decode.cpp -L$(LIBDIR) -lrt_amd -lz -Wl,-rpath,'$$ORIGIN'
+$(LIBDIR)/librt_host.so: $(wildcard $(HOST)/*.cpp) $(wildcard $(HOST)/*.h) include/rt_amd.h $(LIBDIR)/librt_amd.so
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(wildcard $(HOST)/*.cpp) -L$(LIBDIR) -lrt_amd -lz -Wl,-rpath,'$$ORIGIN'
 
 clean:
 	rm -f $(LIBDIR)/*.so

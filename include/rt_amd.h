@@ -86,7 +86,10 @@ typedef struct rt_light {
     int32_t prim;        /* index into the ORIGINAL primitive list */
     float   Le[3];
     int32_t two_sided;
-    float   area;        /* Shape::Area() as the reference caches it */
+    float   area;        /* DiffuseAreaLight::area (light.cpp:35), which only Power() reads.  Not used by the library: sampling
+                            divides by Triangle::Area() computed from the vertices (triangle.cpp:222-227,246), as the reference does */
+    int32_t flip_normal; /* the shape's reverseOrientation ^ transformSwapsHandedness: Triangle::Sample turns the sampled
+                            normal round when the mesh has no vertex normals (triangle.cpp:237-243); Intersect never does */
 } rt_light;
 
 /* The whole scene, flattened.  Primitive arrays are in the ORIGINAL order the
@@ -140,18 +143,23 @@ typedef struct rt_render_opts {
 } rt_render_opts;
 
 enum {
-    RT_RENDER_ACCUMULATE = 1  /* add onto the existing contents of the sum buffer instead of clearing it */
+    RT_RENDER_ACCUMULATE   = 1, /* add onto the existing contents of the sum buffer instead of clearing it */
+    RT_RENDER_TIME_KERNELS = 2  /* bracket every launch with HIP events and fill seconds_trace / _shade / _shadow / _other
+                                   (costs a few percent: the events serialise the launches) */
 };
 
 typedef struct rt_render_stats {
     uint64_t samples;          /* camera paths started */
     uint64_t rays_closest;     /* closest-hit traversals */
     uint64_t rays_shadow;      /* any-hit traversals */
-    uint64_t iterations;       /* wavefront iterations */
+    uint64_t iterations;       /* bounce levels that had launches of their own, summed over passes (the near-empty late
+                                  bounces of a pass run inside one launch and count as one level) */
     double   seconds_total;    /* device time, HIP events on the library's stream */
-    double   seconds_trace;    /* closest-hit kernel  */
-    double   seconds_shade;    /* shading kernels     */
-    double   seconds_shadow;   /* any-hit kernel      */
+    /* The four below are filled only under RT_RENDER_TIME_KERNELS, else 0: */
+    double   seconds_trace;    /* closest-hit kernels (k_extend*)                                          */
+    double   seconds_shade;    /* shading kernels (k_shade*; on scenes that fit LDS they trace the shadow ray too) */
+    double   seconds_shadow;   /* any-hit kernels (k_shadow*)                                              */
+    double   seconds_other;    /* ray generation, late-bounce kernel (k_finish), per-pixel accumulation    */
 } rt_render_stats;
 
 typedef struct rt_trace_stats {
@@ -192,8 +200,15 @@ int rt_bvh_build_ex(int32_t n_prims, const float *prim_bounds, int32_t max_prims
  * (Triangle::WorldBound triangle.cpp:45-50, Shape::WorldBound shape.cpp:16 for spheres). */
 int rt_prim_bounds(const rt_scene_desc *desc, float *bounds_out);
 
+/* The checks rt_scene_create runs before it follows any index of a description: required arrays present, every
+ * primitive / material / texture / light index in range, and (when bvh_nodes is given) a tree the kernels can walk — links
+ * in range and forward, every node and leaf slot reached exactly once, prim_order a permutation, at most 64 interior levels
+ * (the reference's own traversal stack, include/core/bvh.cpp:253).  0 = consistent; otherwise negative and msg (may be NULL)
+ * receives the reason.  Needs no GPU.  The reference has no counterpart: its object graph cannot be inconsistent. */
+int rt_scene_desc_check(const rt_scene_desc *desc, char *msg, size_t msg_cap);
+
 /* Flatten + upload a scene (replaces the pointer graph behind Scene/BVHAccel,
- * include/core/scene.h:9-24, bvh.h:15-37). */
+ * include/core/scene.h:9-24, bvh.h:15-37).  Fails (negative) on a description rt_scene_desc_check rejects. */
 int rt_scene_create(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out);
 void rt_scene_destroy(rt_scene *scene);
 /* Copy the tree the scene uses back to the caller (for parity checks). */

@@ -115,7 +115,7 @@ static void LoadScene(const std::string &path, RefScene &rs) {
         default: fprintf(stderr, "bad material\n"); exit(2);
         }
     }
-    struct LightRec { int32_t prim; float Le[3]; int32_t two; float area; };
+    struct LightRec { int32_t prim; float Le[3]; int32_t two; float area; int32_t flip; };
     auto lrec = r.arr<LightRec>(n_lights);
     rs.lights.resize(n_lights);
     Transform *I = Keep(rs, Transform());
@@ -127,7 +127,9 @@ static void LoadScene(const std::string &path, RefScene &rs) {
             for (int k = 0; k < 3; ++k) { P[k] = Point3f(tri_p[9 * g + 3 * k], tri_p[9 * g + 3 * k + 1], tri_p[9 * g + 3 * k + 2]); UV[k] = Point2f(tri_uv[6 * g + 2 * k], tri_uv[6 * g + 2 * k + 1]); }
             bool hn = has_n && tri_has_n[g];
             if (hn) for (int k = 0; k < 3; ++k) N[k] = Normal3f(tri_n[9 * g + 3 * k], tri_n[9 * g + 3 * k + 1], tri_n[9 * g + 3 * k + 2]);
-            shape = CreateTriangleMesh(I, I, false, 1, idx, 3, P, nullptr, hn ? N : nullptr, UV)[0];
+            // the dump's transforms are the identity, so reverseOrientation alone carries the light's normal flip (triangle.cpp:242-243)
+            bool rev = plight[i] >= 0 && lrec[plight[i]].flip != 0;
+            shape = CreateTriangleMesh(I, I, rev, 1, idx, 3, P, nullptr, hn ? N : nullptr, UV)[0];
         } else {
             const float *s = &spheres[33 * (size_t)geom[i]];
             Float m[4][4], mi[4][4]; memcpy(m, s + 1, 64); memcpy(mi, s + 17, 64);

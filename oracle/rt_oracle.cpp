@@ -1040,7 +1040,7 @@ RGB UniformSampleOneLight(const Scene &sc, const SurfaceInteraction &si, const B
         const float *N = &sc.tri_n[9 * g];
         V3 ns = b0 * mk(N[0], N[1], N[2]) + b1 * mk(N[3], N[4], N[5]) + (1 - b0 - b1) * mk(N[6], N[7], N[8]);
         ln = Faceforward(ln, ns);
-    }
+    } else if (light.flip_normal) ln = -ln;   // reverseOrientation ^ transformSwapsHandedness, triangle.cpp:242-243
     Float area = 0.5 * Length(Cross(p1 - p0, p2 - p0));
     Float pdf = 1 / area;
     // Shape::Sample(ref, u, pdf)

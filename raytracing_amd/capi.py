@@ -36,7 +36,7 @@ class Material(C.Structure):
 
 
 class Light(C.Structure):
-    _fields_ = [("prim", C.c_int32), ("Le", C.c_float * 3), ("two_sided", C.c_int32), ("area", C.c_float)]
+    _fields_ = [("prim", C.c_int32), ("Le", C.c_float * 3), ("two_sided", C.c_int32), ("area", C.c_float), ("flip_normal", C.c_int32)]
 
 
 class SceneDesc(C.Structure):
@@ -67,7 +67,7 @@ class RenderOpts(C.Structure):
 class RenderStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64), ("iterations", C.c_uint64),
                 ("seconds_total", C.c_double), ("seconds_trace", C.c_double), ("seconds_shade", C.c_double),
-                ("seconds_shadow", C.c_double)]
+                ("seconds_shadow", C.c_double), ("seconds_other", C.c_double)]
 
 
 class TraceStats(C.Structure):
@@ -75,10 +75,11 @@ class TraceStats(C.Structure):
 
 
 RT_RENDER_ACCUMULATE = 1
+RT_RENDER_TIME_KERNELS = 2
 
 # Every symbol include/rt_amd.h declares.
 RT_AMD_SYMBOLS = [
-    "rt_version", "rt_init", "rt_shutdown", "rt_last_error", "rt_bvh_build", "rt_bvh_build_ex", "rt_prim_bounds", "rt_scene_create",
+    "rt_version", "rt_init", "rt_shutdown", "rt_last_error", "rt_bvh_build", "rt_bvh_build_ex", "rt_prim_bounds", "rt_scene_desc_check", "rt_scene_create",
     "rt_scene_destroy", "rt_scene_get_bvh", "rt_trace_closest", "rt_trace_any", "rt_trace_closest_device",
     "rt_render", "rt_render_device", "rt_tonemap_u8",
 ]
@@ -102,6 +103,7 @@ def load_rt_amd():
     lib.rt_bvh_build.argtypes = [C.c_int32, f32p, C.POINTER(BvhNode), i32p, i32p]
     lib.rt_bvh_build_ex.argtypes = [C.c_int32, f32p, C.c_int32, C.c_int32, C.POINTER(BvhNode), i32p, i32p]
     lib.rt_prim_bounds.argtypes = [C.POINTER(SceneDesc), f32p]
+    lib.rt_scene_desc_check.argtypes = [C.POINTER(SceneDesc), C.c_char_p, C.c_size_t]
     lib.rt_scene_create.argtypes = [vp, C.POINTER(SceneDesc), C.POINTER(vp)]
     lib.rt_scene_destroy.argtypes = [vp]; lib.rt_scene_destroy.restype = None
     lib.rt_scene_get_bvh.argtypes = [vp, C.POINTER(BvhNode), i32p, i32p]

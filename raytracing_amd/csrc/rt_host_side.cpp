@@ -158,7 +158,12 @@ int rt_bvh_build(int32_t n, const float *prim_bounds, rt_bvh_node *nodes_out, in
 }
 
 int rt_prim_bounds(const rt_scene_desc *d, float *out) {
-    if (!d || !out) return -1;
+    if (!d || !out || d->n_prims < 0 || (d->n_prims > 0 && (!d->prim_kind || !d->prim_geom))) return -1;
+    for (int32_t i = 0; i < d->n_prims; ++i) {       // nothing is read through an index that has not been checked
+        const int g = d->prim_geom[i];
+        if (d->prim_kind[i] == RT_PRIM_TRIANGLE ? (!d->tri_p || g < 0 || g >= d->n_tris)
+                                                : (d->prim_kind[i] != RT_PRIM_SPHERE || !d->spheres || g < 0 || g >= d->n_spheres)) return -1;
+    }
     for (int32_t i = 0; i < d->n_prims; ++i) {
         Box b; b.reset();
         if (d->prim_kind[i] == RT_PRIM_TRIANGLE) {

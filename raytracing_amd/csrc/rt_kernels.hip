@@ -54,7 +54,7 @@ struct BounceCounts {
     uint32_t shadow[RT_SEG_BLOCKS];                   // shadow rays produced by this bounce
     uint32_t cls[RT_NUM_CLASSES][RT_SEG_BLOCKS];      // paths per material class
 };
-struct BounceStats { uint32_t n_queue, n_shadow, stack_overflow, pad; };
+struct BounceStats { uint32_t n_queue, n_shadow, pad0, pad1; };
 
 struct PathQueue {   // SoA, capacity = cap
     float *ox, *oy, *oz, *dx, *dy, *dz, *tr, *tg, *tb;
@@ -1405,6 +1405,32 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate_wave(const float4 *lbuf
 }
 
 // ==================================================================== host ==
+// Two HIP events that are destroyed on every way out of the function that owns them.
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t create() { hipError_t e = hipEventCreate(&a); return e != hipSuccess ? e : hipEventCreate(&b); }
+    ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+// Per-class kernel times of a pass (RT_RENDER_TIME_KERNELS): an event after every launch, tagged with the class of that launch;
+// the time between two consecutive events goes to the later one's class.
+enum { RT_TIME_TRACE = 0, RT_TIME_SHADE = 1, RT_TIME_SHADOW = 2, RT_TIME_OTHER = 3 };
+struct KernelTimer {
+    bool on = false; hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> ev; std::vector<int> tag; size_t used = 0;
+    double seconds[4] = {0, 0, 0, 0};
+    ~KernelTimer() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+    void mark(int cls) {
+        if (!on) return;
+        if (used == ev.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } ev.push_back(e); tag.push_back(0); }
+        tag[used] = cls; (void)hipEventRecord(ev[used++], stream);
+    }
+    void begin_pass() { used = 0; mark(RT_TIME_OTHER); }
+    void end_pass() {      // the stream has been synchronised
+        for (size_t i = 1; i < used; ++i) { float ms = 0.f; if (hipEventElapsedTime(&ms, ev[i - 1], ev[i]) == hipSuccess) seconds[tag[i]] += (double)ms * 1e-3; }
+        used = 0;
+    }
+};
+
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1493,7 +1519,80 @@ bool triangle_frame(const float *P, const float *UV, H3 *n, H3 *ss, H3 *ts) {
 bool is_affine(const float *m) { return m[12] == 0.f && m[13] == 0.f && m[14] == 0.f && m[15] == 1.f; }
 }  // namespace
 
+// Everything rt_scene_create follows through the description: required arrays present, counts sane, every index in range.
+// Returns the complaint, or an empty string.
+static std::string check_desc(const rt_scene_desc *d) {
+    if (d->n_prims <= 0) return "empty scene";
+    if (!d->prim_kind || !d->prim_geom || !d->prim_material || !d->prim_light) return "a per-primitive array is NULL";
+    if (d->n_tris < 0 || d->n_spheres < 0 || d->n_materials <= 0 || d->n_textures < 0 || d->n_lights < 0) return "negative or zero table size";
+    if (d->n_tris > 0 && (!d->tri_p || !d->tri_uv)) return "tri_p / tri_uv is NULL";
+    if (d->n_spheres > 0 && !d->spheres) return "spheres is NULL";
+    if (!d->materials || (d->n_textures > 0 && !d->textures) || (d->n_lights > 0 && !d->lights)) return "materials / textures / lights is NULL";
+    if (d->bvh_nodes && (!d->prim_order || d->n_nodes <= 0)) return "bvh_nodes given without prim_order";
+    for (int i = 0; i < d->n_prims; ++i) {
+        int g = d->prim_geom[i], k = d->prim_kind[i], m = d->prim_material[i], l = d->prim_light[i];
+        if (k != RT_PRIM_TRIANGLE && k != RT_PRIM_SPHERE) return "unknown primitive kind";
+        if (g < 0 || g >= (k == RT_PRIM_TRIANGLE ? d->n_tris : d->n_spheres)) return "primitive references out of range (geometry)";
+        if (m < 0 || m >= d->n_materials) return "primitive references out of range (material)";
+        if (l < -1 || l >= d->n_lights) return "primitive references out of range (light)";
+    }
+    for (int i = 0; i < d->n_materials; ++i) {
+        const rt_material &m = d->materials[i];
+        if (m.kind < 0 || m.kind >= RT_NUM_CLASSES) return "unknown material kind";
+        int need = m.kind == RT_MAT_MATTE || m.kind == RT_MAT_MIRROR ? 1 : m.kind == RT_MAT_GLASS || m.kind == RT_MAT_PLASTIC ? 3 : m.kind == RT_MAT_METAL ? 4 : 1;
+        for (int k = 0; k < 4; ++k)
+            if (m.tex[k] >= d->n_textures || m.tex[k] < -1 || (k < need && m.tex[k] < 0)) return "material texture slot out of range";
+    }
+    for (int i = 0; i < d->n_lights; ++i) {
+        const rt_light &L = d->lights[i];
+        if (L.prim < 0 || L.prim >= d->n_prims || d->prim_kind[L.prim] != RT_PRIM_TRIANGLE) return "area lights must be triangles";
+        if (d->prim_light[L.prim] != i) return "a light's primitive does not point back at the light";
+    }
+    return "";
+}
+
+// A tree the kernels can walk: links in range and forward (so every walk terminates), every node reached exactly once from
+// the root, every leaf slot covered exactly once, prim_order a permutation, and no more interior levels than a traversal
+// stack holds (a walk keeps at most one pending node per interior level; the reference's own stack is nodesToVisit[64],
+// bvh.cpp:253).  *interior_levels receives the number of interior levels.
+static std::string check_tree(const rt_bvh_node *nodes, int nn, const int32_t *order, int n_prims, int *interior_levels) {
+    if (nn <= 0) return "empty tree";
+    if (nn > 2 * n_prims - 1) return "more nodes than a binary tree over the primitives can have";
+    for (int i = 0; i < nn; ++i) {
+        const rt_bvh_node &nd = nodes[i];
+        if (nd.nprim > 0) { if (nd.offset < 0 || nd.offset + nd.nprim > n_prims) return "leaf range out of bounds"; }
+        else if (nd.offset <= i + 1 || nd.offset >= nn || i + 1 >= nn || nd.axis > 2) return "interior node links out of bounds";
+    }
+    std::vector<uint8_t> seen_node(nn, 0), seen_slot(n_prims, 0), seen_prim(n_prims, 0);
+    std::vector<std::pair<int, int>> todo; todo.push_back({0, 1});
+    int deepest = 0;
+    while (!todo.empty()) {
+        auto [i, level] = todo.back(); todo.pop_back();
+        if (seen_node[i]++) return "a node is reachable twice";
+        const rt_bvh_node &nd = nodes[i];
+        if (nd.nprim > 0) { for (int k = 0; k < nd.nprim; ++k) if (seen_slot[nd.offset + k]++) return "two leaves share a slot"; }
+        else { deepest = std::max(deepest, level); todo.push_back({nd.offset, level + 1}); todo.push_back({i + 1, level + 1}); }
+    }
+    for (int i = 0; i < nn; ++i) if (!seen_node[i]) return "a node is not reachable from the root";
+    for (int i = 0; i < n_prims; ++i) {
+        if (!seen_slot[i]) return "a leaf slot is covered by no leaf";
+        int p = order[i];
+        if (p < 0 || p >= n_prims || seen_prim[p]++) return "prim_order is not a permutation";
+    }
+    if (deepest > RT_MAX_STACK) return "tree deeper than the 64-entry traversal stack";
+    if (interior_levels) *interior_levels = deepest;
+    return "";
+}
+
 extern "C" {
+
+// Host-only: what rt_scene_create checks before it follows any index.
+int rt_scene_desc_check(const rt_scene_desc *d, char *msg, size_t msg_cap) {
+    std::string why = d ? check_desc(d) : std::string("NULL description");
+    if (why.empty() && d->bvh_nodes) why = check_tree(d->bvh_nodes, d->n_nodes, d->prim_order, d->n_prims, nullptr);
+    if (msg && msg_cap) snprintf(msg, msg_cap, "%s", why.c_str());
+    return why.empty() ? 0 : -1;
+}
 
 const char *rt_last_error(rt_ctx *ctx) { return ctx ? ctx->error.c_str() : g_init_error.c_str(); }
 
@@ -1522,43 +1621,24 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     if (!this_ || !d || !out) return -1;
     rt_ctx *ctx = this_;
     HIP_OK(hipSetDevice(ctx->device));
-    if (d->n_prims <= 0) { set_error(ctx, "rt_scene_create: empty scene"); return -1; }
+    // every index of the description is checked here, in original primitive order, before anything follows it
+    // (rt_prim_bounds and the tree builder below read through prim_kind / prim_geom)
+    { std::string why = check_desc(d); if (!why.empty()) { set_error(ctx, "rt_scene_create: " + why); return -1; } }
     std::unique_ptr<rt_scene> sc(new rt_scene);
     sc->ctx = ctx; sc->n_prims = d->n_prims;
     if (d->bvh_nodes) {
-        if (!d->prim_order || d->n_nodes <= 0) { set_error(ctx, "rt_scene_create: bvh_nodes given without prim_order"); return -1; }
         sc->nodes.assign(d->bvh_nodes, d->bvh_nodes + d->n_nodes); sc->order.assign(d->prim_order, d->prim_order + d->n_prims);
     } else {
         std::vector<float> pb(6 * (size_t)d->n_prims);
-        rt_prim_bounds(d, pb.data());
+        if (rt_prim_bounds(d, pb.data()) != 0) { set_error(ctx, "rt_scene_create: rt_prim_bounds failed"); return -1; }
         sc->nodes.resize(2 * (size_t)d->n_prims); sc->order.resize(d->n_prims);
         int32_t nn = 0;
         if (rt_bvh_build(d->n_prims, pb.data(), sc->nodes.data(), &nn, sc->order.data()) != 0) { set_error(ctx, "rt_bvh_build failed"); return -1; }
         sc->nodes.resize(nn);
     }
-    // validate the tree before any kernel walks it
     int nn = (int)sc->nodes.size();
-    for (int i = 0; i < nn; ++i) {
-        const rt_bvh_node &nd = sc->nodes[i];
-        if (nd.nprim > 0) { if (nd.offset < 0 || nd.offset + nd.nprim > d->n_prims) { set_error(ctx, "rt_scene_create: leaf range out of bounds"); return -1; } }
-        else if (nd.offset <= i || nd.offset >= nn || i + 1 >= nn || nd.axis > 2) { set_error(ctx, "rt_scene_create: interior node links out of bounds"); return -1; }
-    }
-    for (int i = 0; i < d->n_prims; ++i) {
-        int p = sc->order[i];
-        if (p < 0 || p >= d->n_prims) { set_error(ctx, "rt_scene_create: prim_order out of range"); return -1; }
-        int g = d->prim_geom[p], k = d->prim_kind[p], m = d->prim_material[p], l = d->prim_light[p];
-        if ((k == RT_PRIM_TRIANGLE && (g < 0 || g >= d->n_tris)) || (k == RT_PRIM_SPHERE && (g < 0 || g >= d->n_spheres)) || (k != RT_PRIM_TRIANGLE && k != RT_PRIM_SPHERE) ||
-            m < 0 || m >= d->n_materials || l >= d->n_lights) { set_error(ctx, "rt_scene_create: primitive references out of range"); return -1; }
-    }
-    for (int i = 0; i < d->n_materials; ++i) {
-        const rt_material &m = d->materials[i];
-        if (m.kind < 0 || m.kind >= RT_NUM_CLASSES) { set_error(ctx, "rt_scene_create: unknown material kind"); return -1; }
-        int need = m.kind == RT_MAT_MATTE || m.kind == RT_MAT_MIRROR ? 1 : m.kind == RT_MAT_GLASS || m.kind == RT_MAT_PLASTIC ? 3 : m.kind == RT_MAT_METAL ? 4 : 1;
-        for (int k = 0; k < 4; ++k) {
-            if (m.tex[k] >= d->n_textures || (k < need && m.tex[k] < 0)) { set_error(ctx, "rt_scene_create: material texture slot out of range"); return -1; }
-        }
-        sc->classes[m.kind] = true;
-    }
+    { std::string why = check_tree(sc->nodes.data(), nn, sc->order.data(), d->n_prims, &sc->interior_depth); if (!why.empty()) { set_error(ctx, "rt_scene_create: " + why); return -1; } }
+    for (int i = 0; i < d->n_materials; ++i) sc->classes[d->materials[i].kind] = true;
     // slots
     size_t ns = (size_t)d->n_prims;
     std::vector<float> slots(12 * ns), frames(12 * ns, 0.f), uv(6 * ns, 0.f);
@@ -1598,6 +1678,7 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
         D.area = (float)(0.5 * std::sqrt(hlen2(c)));
         if (!(D.area > 0.f)) { set_error(ctx, "rt_scene_create: degenerate light triangle"); return -1; }
         if (d->tri_n && d->tri_has_n && d->tri_has_n[g]) { D.has_n = 1; memcpy(D.vn, d->tri_n + 9 * g, 36); }
+        else if (L.flip_normal) { D.n[0] = -n.x; D.n[1] = -n.y; D.n[2] = -n.z; }      // triangle.cpp:242-243
         D.Le[0] = L.Le[0]; D.Le[1] = L.Le[1]; D.Le[2] = L.Le[2]; D.two_sided = L.two_sided;
     }
     std::vector<DevTexture> tex((size_t)std::max(1, d->n_textures));
@@ -1656,17 +1737,6 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     // quad nodes: one 128-byte record per even-depth interior node with the boxes of its four grandchildren.  Only for trees
     // whose interior boxes are bit for bit the min/max of their children's (true of every tree rt_bvh_build makes).
     std::vector<float> quads;
-    {   // interior levels of the tree = most entries a pair stack can hold at once
-        std::vector<std::pair<int, int>> todo; todo.push_back({0, 1});
-        int deepest = 0;
-        while (!todo.empty()) {
-            auto [node, level] = todo.back(); todo.pop_back();
-            if (sc->nodes[node].nprim != 0) continue;
-            deepest = std::max(deepest, level);
-            todo.push_back({node + 1, level + 1}); todo.push_back({sc->nodes[node].offset, level + 1});
-        }
-        sc->interior_depth = deepest;
-    }
     int n_quads = 0, tree_depth = 0;
     bool quads_ok = sc->nodes[0].nprim == 0;
     if (quads_ok) {
@@ -1828,17 +1898,16 @@ int rt_trace_closest_device(rt_scene *this_, size_t n, const void *rays, void *h
         HIP_OK(hipStreamSynchronize(ctx->stream));
         if (stats) { stats->nodes_visited = w[0]; stats->prims_tested = w[1]; }
     }
-    hipEvent_t e0, e1;
-    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
-    HIP_OK(hipEventRecord(e0, ctx->stream));
+    EventPair ev;
+    HIP_OK(ev.create());
+    HIP_OK(hipEventRecord(ev.a, ctx->stream));
     for (int r = 0; r < repeats; ++r)
         launch_trace<false, false>(this_, grid, n, (const float *)rays, 0, prim, t, b1, b2, nullptr, nullptr);
-    HIP_OK(hipEventRecord(e1, ctx->stream));
-    HIP_OK(hipEventSynchronize(e1));
+    HIP_OK(hipEventRecord(ev.b, ctx->stream));
+    HIP_OK(hipEventSynchronize(ev.b));
     HIP_OK(hipGetLastError());
     float ms = 0.f;
-    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIP_OK(hipEventElapsedTime(&ms, ev.a, ev.b));
     if (stats) stats->seconds = (double)ms * 1e-3 / repeats;
     return 0;
 }
@@ -1951,9 +2020,10 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     rp.width = W; rp.height = H; rp.strata_x = o->strata_x; rp.strata_y = o->strata_y; rp.max_depth = o->max_depth; rp.k0 = o->seed_lo; rp.k1 = o->seed_hi;
 
     rt_render_stats st; memset(&st, 0, sizeof(st));
-    hipEvent_t e0, e1;
-    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
-    HIP_OK(hipEventRecord(e0, ctx->stream));
+    EventPair ev;
+    HIP_OK(ev.create());
+    HIP_OK(hipEventRecord(ev.a, ctx->stream));
+    KernelTimer tm; tm.on = (o->flags & RT_RENDER_TIME_KERNELS) != 0; tm.stream = ctx->stream;
     std::vector<BounceStats> hs(n_bounce);
     const uint32_t ucap = (uint32_t)wcap, useg = (uint32_t)segcap;
     // scenes small enough are traversed out of an LDS copy (no spheres: their records stay in global memory)
@@ -1988,7 +2058,9 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
         int cur = std::min(spb, o->sample_end - s0);
         rp.spb = cur; rp.sample0 = s0; rp.n_paths = (uint32_t)(npix * (size_t)cur);
         HIP_OK(hipMemsetAsync(bstats, 0, stats_bytes, ctx->stream));
+        tm.begin_pass();
         hipLaunchKernelGGL(k_raygen, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, rp, q[0], useg, lbuf, counts);
+        tm.mark(RT_TIME_OTHER);
         int cq = 0;
         // k_finish takes over at the first bounce expected to hold no more than two chunks of 64 paths per wave of the grid
         int finish_at = 1 << 30;
@@ -2003,6 +2075,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                 else
                     hipLaunchKernelGGL(k_finish<false>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], useg, lbuf, counts, bstats,
                                        (int *)this_->d_spill.p);
+                tm.mark(RT_TIME_OTHER);
                 break;
             }
             if (frame_old || b < round_bounces) {
@@ -2021,6 +2094,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
             else
                 hipLaunchKernelGGL(k_extend_pl<RT_WALK_PAIRS>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
                                    (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
+            tm.mark(RT_TIME_TRACE);
             if (b < o->max_depth) {
                 if (this_->classes[RT_MAT_MATTE]) launch_shade<RT_MAT_MATTE>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
                 if (this_->classes[RT_MAT_MIRROR] && !rp.merge_mirror) launch_shade<RT_MAT_MIRROR>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
@@ -2028,6 +2102,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                 if (this_->classes[RT_MAT_METAL]) launch_shade<RT_MAT_METAL>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
                 if (this_->classes[RT_MAT_PLASTIC]) launch_shade<RT_MAT_PLASTIC>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
                 if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
+                tm.mark(RT_TIME_SHADE);
                 if (this_->dev.n_lights > 0 && !fuse_shadow) {
                     if (frame_old || b < round_bounces) {
                         if (lds_scene)
@@ -2042,6 +2117,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                     else
                         hipLaunchKernelGGL(k_shadow_pl<RT_WALK_PAIRS>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, hb.slot, useg, lbuf,
                                            counts, bstats, (int *)this_->d_spill.p);
+                    tm.mark(RT_TIME_SHADOW);
                 }
             }
             cq ^= 1;
@@ -2053,9 +2129,11 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
             int ag = (int)std::min<size_t>((npix + RT_BLOCK - 1) / RT_BLOCK, (size_t)grid * 4);
             hipLaunchKernelGGL(k_accumulate, dim3(ag), dim3(RT_BLOCK), 0, ctx->stream, (const float4 *)lbuf, cur, (uint32_t)npix, (float *)this_->d_sum.p);
         }
+        tm.mark(RT_TIME_OTHER);
         HIP_OK(hipGetLastError());
         HIP_OK(hipMemcpyAsync(hs.data(), bstats, stats_bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIP_OK(hipStreamSynchronize(ctx->stream));
+        tm.end_pass();
         st.samples += rp.n_paths;
         for (size_t b = 0; b < n_bounce; ++b) { st.rays_closest += hs[b].n_queue; st.rays_shadow += hs[b].n_shadow; if (hs[b].n_queue) st.iterations++; }
         if (use_finish && finish_at == 1 << 30 && rp.n_paths >= 4096) {       // a pass through every bounce: note how fast the paths die out
@@ -2063,12 +2141,13 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
             for (int b = 0; b <= o->max_depth; ++b) this_->survival[b] = (float)((double)hs[b].n_queue / rp.n_paths);
         }
     }
-    HIP_OK(hipEventRecord(e1, ctx->stream));
-    HIP_OK(hipEventSynchronize(e1));
+    HIP_OK(hipEventRecord(ev.b, ctx->stream));
+    HIP_OK(hipEventSynchronize(ev.b));
     float ms = 0.f;
-    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIP_OK(hipEventElapsedTime(&ms, ev.a, ev.b));
     st.seconds_total = (double)ms * 1e-3;
+    st.seconds_trace = tm.seconds[RT_TIME_TRACE]; st.seconds_shade = tm.seconds[RT_TIME_SHADE]; st.seconds_shadow = tm.seconds[RT_TIME_SHADOW];
+    st.seconds_other = tm.seconds[RT_TIME_OTHER];
     if (stats) *stats = st;
     *out_device_sum = this_->d_sum.p;
     return 0;

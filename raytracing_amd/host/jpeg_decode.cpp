@@ -11,6 +11,7 @@
 //   * YCbCr -> RGB: 16-bit fixed-point tables (1.402, 1.772, 0.71414, 0.34414), rounding as in jdcolor.c.
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <vector>
 
 #include "rt_host.h"
@@ -113,8 +114,11 @@ struct Decoder {
     }
 
     // ---- block decoders (T.81 F.2.2, G.1.2) ----
+    // A DC difference category above 11 cannot come from 8-bit samples (T.81 Table F.1); a corrupt table that yields one would
+    // turn into shifts by negative amounts below.
     void block_baseline(Component &c, int16_t *b, int td, int ta) {
         int s = decode(dc[td]);
+        if (s > 11) { ok = false; return; }
         c.pred += extend(getbits(s), s);
         b[0] = (int16_t)c.pred;
         for (int k = 1; k < 64; ++k) {
@@ -126,6 +130,7 @@ struct Decoder {
     }
     void block_dc_first(Component &c, int16_t *b, int td, int al) {
         int s = decode(dc[td]);
+        if (s > 11) { ok = false; return; }
         c.pred += extend(getbits(s), s);
         b[0] = (int16_t)(c.pred * (1 << al));
     }
@@ -232,6 +237,7 @@ struct Decoder {
                 progressive = m == 0xC2;
                 int prec = u8(); H = u16(); W = u16(); ncomp = u8();
                 if (prec != 8 || W <= 0 || H <= 0 || (ncomp != 1 && ncomp != 3)) return false;
+                if ((size_t)W * (size_t)H > ((size_t)1 << 28)) return false;     // 268 M texels: beyond any texture, and the buffers below scale with it
                 for (int c = 0; c < ncomp; ++c) {
                     comp[c].id = u8(); int hv = u8(); comp[c].h = hv >> 4; comp[c].v = hv & 15; comp[c].tq = u8();
                     if (comp[c].h < 1 || comp[c].h > 2 || comp[c].v < 1 || comp[c].v > 2 || comp[c].tq > 3) return false;
@@ -397,8 +403,10 @@ struct Decoder {
 
 bool DecodeJPEG(const uint8_t *data, size_t size, int *width, int *height, std::vector<uint8_t> *rgb) {
     if (!data || !width || !height || !rgb) return false;
-    Decoder dec(data, size);
-    if (!dec.headers_and_scans() || !dec.reconstruct() || !dec.to_rgb(rgb)) return false;
-    *width = dec.W; *height = dec.H;
+    try {
+        Decoder dec(data, size);
+        if (!dec.headers_and_scans() || !dec.reconstruct() || !dec.to_rgb(rgb)) return false;
+        *width = dec.W; *height = dec.H;
+    } catch (std::exception &) { return false; }      // allocation failure on a hostile header
     return true;
 }

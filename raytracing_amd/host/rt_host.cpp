@@ -45,13 +45,13 @@ Matrix4x4 Inverse(const Matrix4x4 &src) {
                 if (used[c] == 0) {
                     if (std::abs(a[r][c]) >= best) { best = Float(std::abs(a[r][c])); prow = r; pcol = c; }
                 } else if (used[c] > 1)
-                    printf("Singular matrix in MatrixInvert\n");
+                    fprintf(stderr, "Inverse: matrix has no inverse (a pivot column was chosen twice)\n");
             }
         }
         ++used[pcol];
         if (prow != pcol) for (int k = 0; k < 4; ++k) std::swap(a[prow][k], a[pcol][k]);
         rowOf[step] = prow; colOf[step] = pcol;
-        if (a[pcol][pcol] == 0.f) printf("Singular matrix in MatrixInvert\n");
+        if (a[pcol][pcol] == 0.f) fprintf(stderr, "Inverse: matrix has no inverse (zero pivot)\n");
         Float pivinv = 1. / a[pcol][pcol];
         a[pcol][pcol] = 1.;
         for (int k = 0; k < 4; ++k) a[pcol][k] *= pivinv;
@@ -130,7 +130,7 @@ Transform LookAt(const Point3f &pos, const Point3f &look, const Vector3f &up) {
     c2w.m[0][3] = pos.x; c2w.m[1][3] = pos.y; c2w.m[2][3] = pos.z; c2w.m[3][3] = 1;
     Vector3f dir = Normalize(look - pos);
     if (Cross(Normalize(up), dir).Length() == 0) {
-        printf("up vector and viewing direction passed to LookAt are pointing in the same direction.  Using the identity transformation.\n");
+        fprintf(stderr, "LookAt: the up vector is parallel to the viewing direction; returning the identity\n");
         return Transform();
     }
     Vector3f right = Normalize(Cross(Normalize(up), dir));
@@ -428,6 +428,7 @@ std::unique_ptr<FlatScene> FlattenScene(const Scene &scene) {
             if (kind != RT_PRIM_TRIANGLE) throw std::runtime_error("FlattenScene: area lights must be triangles");
             rt_light &L = fs->lights[li];
             L.prim = (int32_t)i; L.Le[0] = dl->Lemit[0]; L.Le[1] = dl->Lemit[1]; L.Le[2] = dl->Lemit[2]; L.two_sided = dl->twoSided; L.area = dl->area;
+            L.flip_normal = (gp->shape->reverseOrientation ^ gp->shape->transformSwapsHandedness) ? 1 : 0;
         }
         fs->prim_light.push_back(li);
     }
@@ -621,17 +622,28 @@ void ModelLoad::loadModel(string path, const Transform &ObjectToWorld) {
     }
     const JVal *views = root.get("bufferViews"), *accs = root.get("accessors"), *jmeshes = root.get("meshes");
     if (!views || !accs || !jmeshes) { std::cout << "ERROR::GLTF::incomplete scene" << std::endl; return; }
+    // Start of an accessor's data, or nullptr unless every element lies inside both its buffer view and its buffer.
     auto accessor = [&](int idx, int *count, int *ctype, int *ncomp, int *stride) -> const uint8_t * {
         if (idx < 0 || idx >= (int)accs->a.size()) return nullptr;
-        const JVal &a = accs->a[idx]; const JVal &v = views->a[a.geti("bufferView", 0)];
+        const JVal &a = accs->a[idx];
+        const int vi = a.geti("bufferView", -1);
+        if (vi < 0 || vi >= (int)views->a.size()) return nullptr;
+        const JVal &v = views->a[vi];
+        const int bi = v.geti("buffer", 0);
+        if (bi < 0 || bi >= (int)buffers.size()) return nullptr;
         *count = a.geti("count", 0); *ctype = a.geti("componentType", 0);
+        if (*count <= 0) return nullptr;
         const std::string ty = a.get("type") ? a.get("type")->s : "SCALAR";
         *ncomp = ty == "SCALAR" ? 1 : ty == "VEC2" ? 2 : ty == "VEC3" ? 3 : 4;
         int csize = (*ctype == 5126 || *ctype == 5125) ? 4 : (*ctype == 5123 || *ctype == 5122) ? 2 : 1;
-        int bs = v.geti("byteStride", 0); *stride = bs ? bs : csize * *ncomp;
-        const std::vector<uint8_t> &buf = buffers[v.geti("buffer", 0)];
-        size_t off = (size_t)v.geti("byteOffset", 0) + (size_t)a.geti("byteOffset", 0);
-        if (off + (size_t)*stride * (*count ? *count - 1 : 0) > buf.size()) return nullptr;
+        int bs = v.geti("byteStride", 0);
+        if (bs < 0 || v.geti("byteOffset", 0) < 0 || a.geti("byteOffset", 0) < 0 || v.geti("byteLength", 0) < 0) return nullptr;
+        *stride = bs ? bs : csize * *ncomp;
+        const std::vector<uint8_t> &buf = buffers[bi];
+        const size_t voff = (size_t)v.geti("byteOffset", 0), off = voff + (size_t)a.geti("byteOffset", 0);
+        const size_t vend = v.get("byteLength") ? voff + (size_t)v.geti("byteLength", 0) : buf.size();
+        const size_t last = off + (size_t)*stride * (size_t)(*count - 1) + (size_t)csize * (size_t)*ncomp;    // one past the last element's last byte
+        if (last > std::min(buf.size(), vend)) return nullptr;
         return buf.data() + off;
     };
     auto texName = [&](const JVal *matl, const char *slot) -> std::string {
@@ -709,6 +721,10 @@ void ModelLoad::loadModel(string path, const Transform &ObjectToWorld) {
                     else idx[i] = ip[(size_t)i * st];
                 }
             } else { idx.resize(nVerts); for (int i = 0; i < nVerts; ++i) idx[i] = i; }
+            idx.resize(idx.size() / 3 * 3);
+            bool idxOk = true;
+            for (int v : idx) if (v < 0 || v >= nVerts) { idxOk = false; break; }
+            if (!idxOk) { std::cout << "ERROR::GLTF::a primitive's indices point outside its vertices; skipped" << std::endl; continue; }
             int nTris = (int)idx.size() / 3;
             meshes.push_back(std::make_shared<TriangleMesh>(ObjectToWorld, nTris, idx.data(), nVerts, P.data(), nullptr, N.empty() ? nullptr : N.data(),
                                                             UV.empty() ? nullptr : UV.data(), nullptr));

@@ -232,7 +232,7 @@ int rth_model_probe(const char *path, int apply_node_transforms, int *n_tris, fl
     if (!path || !n_tris) return -1;
     ModelLoad ML; ML.applyNodeTransforms = apply_node_transforms != 0;
     Transform id;
-    ML.loadModel(path, id);
+    try { ML.loadModel(path, id); } catch (std::exception &e) { g_error = e.what(); return -1; }     // no exception crosses the C boundary
     if (ML.meshes.empty()) return -1;
     int n = 0;
     for (auto &m : ML.meshes) {
@@ -253,7 +253,12 @@ int rth_model_probe(const char *path, int apply_node_transforms, int *n_tris, fl
 int rth_decode_image(const uint8_t *data, size_t size, int *w, int *h, uint8_t *out) {
     static thread_local std::vector<uint8_t> last; static thread_local const uint8_t *last_data = nullptr; static thread_local int lw = 0, lh = 0;
     if (!data || !w || !h) return -1;
-    if (last_data != data || last.empty()) { if (!DecodeImageRGB8(data, size, &lw, &lh, &last)) { last.clear(); last_data = nullptr; return -1; } last_data = data; }
+    if (last_data != data || last.empty()) {
+        bool ok = false;
+        try { ok = DecodeImageRGB8(data, size, &lw, &lh, &last); } catch (std::exception &e) { g_error = e.what(); }
+        if (!ok) { last.clear(); last_data = nullptr; return -1; }
+        last_data = data;
+    }
     *w = lw; *h = lh;
     if (out) { memcpy(out, last.data(), last.size()); last.clear(); last_data = nullptr; }
     return 0;

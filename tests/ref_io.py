@@ -59,7 +59,7 @@ def dump_scene(scene, path, tmp):
         out.append(struct.pack("<3i3f4fi", t.kind, t.width, t.height, *list(t.value), t.su, t.sv, t.du, t.dv, len(png)) + png)
     for i in range(d.n_lights):
         L = d.lights[i]
-        out.append(struct.pack("<i3fif", L.prim, *list(L.Le), L.two_sided, L.area))
+        out.append(struct.pack("<i3fifi", L.prim, *list(L.Le), L.two_sided, L.area, L.flip_normal))
     with open(path, "wb") as f:
         f.write(b"".join(out))
 

@@ -50,7 +50,7 @@ def _sections(scene, w=800, h=800):
         t = d.textures[i]
         tex += struct.pack("<i3f2i", t.kind, *list(t.value), t.width, t.height)
     out["textures"] = tex
-    out["lights"] = C.string_at(d.lights, 24 * d.n_lights) if d.n_lights else b""
+    out["lights"] = C.string_at(d.lights, C.sizeof(capi.Light) * d.n_lights) if d.n_lights else b""
     out["camera"] = bytes(scene.camera(w, h))
     return out
 

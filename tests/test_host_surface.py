@@ -25,13 +25,20 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.rt_version()
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors have the sizes the C compiler gives the structs of rt_amd.h (a one-line C program prints them)."""
+    import subprocess
+    names = [("rt_bvh_node", capi.BvhNode), ("rt_sphere", capi.Sphere), ("rt_texture", capi.Texture), ("rt_material", capi.Material),
+             ("rt_light", capi.Light), ("rt_scene_desc", capi.SceneDesc), ("rt_camera", capi.Camera), ("rt_render_opts", capi.RenderOpts),
+             ("rt_render_stats", capi.RenderStats), ("rt_trace_stats", capi.TraceStats)]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "rt_amd.h"\nint main(void){' + "".join('printf("%%zu\\n", sizeof(%s));' % n for n, _ in names) + "return 0;}\n")
+    exe = str(tmp_path / "sizes")
+    subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe])
+    sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    for (n, cls), sz in zip(names, sizes):
+        assert C.sizeof(cls) == sz, n
     assert C.sizeof(capi.BvhNode) == 32
-    assert C.sizeof(capi.Sphere) == 132
-    assert C.sizeof(capi.Material) == 28
-    assert C.sizeof(capi.Light) == 24
-    assert C.sizeof(capi.Camera) == 136
-    assert C.sizeof(capi.RenderOpts) == 36
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
