@@ -234,6 +234,17 @@ int rt_trace_any(rt_scene *scene, size_t n, const float *o, const float *d, cons
 int rt_trace_closest_device(rt_scene *scene, size_t n, const void *rays, void *hits,
                             int repeats, int count_work, rt_trace_stats *stats);
 
+/* rt_trace_closest_device (count_work / stats as there, one launch, same rays / hits layout, synchronous) for callers that
+ * cannot allocate device memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has
+ * no counterpart in the reference.  The call allocates nothing: the traversal stacks' spill area and the work counters, which
+ * the other entry points keep in buffers the library allocates, live in a static array of 32 MiB + 256 bytes in device memory
+ * that every GPU the library runs on holds until the process ends (its address is taken once per context, in rt_init).  The
+ * kernels and their results are those of rt_trace_closest_device; only the grid is cut down to the lanes whose stacks fit the
+ * array (never below 256 blocks).  Limits, refused with an error: n > 2^28 rays; count_work without stats.  All calls on one
+ * GPU share that GPU's array, so calls that overlap on one GPU (two contexts on the same device, from two threads) race; the
+ * array keeps the last call's contents, and the call clears the part that must start at zero (the counters). */
+int rt_trace_closest_device_noalloc(rt_scene *scene, size_t n, const void *rays, void *hits, int count_work, rt_trace_stats *stats);
+
 /* Render samples [sample_begin, sample_end) of every pixel and return the
  * per-pixel SUM of radiance (not the mean) — the loop of
  * SamplerIntegrator::Render / render_pixel (include/core/integrator.cpp:317-412)

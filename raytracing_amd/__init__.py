@@ -224,6 +224,12 @@ class DeviceScene:
                                                C.byref(st)), "rt_trace_closest_device")
         return st
 
+    def trace_closest_device_noalloc(self, n, rays_ptr, hits_ptr, count_work=False, want_stats=True):
+        st = TraceStats()
+        self._chk(rt().rt_trace_closest_device_noalloc(self._p, n, C.c_void_p(rays_ptr), C.c_void_p(hits_ptr), int(count_work),
+                                                       C.byref(st) if want_stats else None), "rt_trace_closest_device_noalloc")
+        return st
+
     def render(self, cam, opts):
         out = np.zeros((cam.height, cam.width, 3), np.float32)
         st = RenderStats()

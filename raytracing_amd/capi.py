@@ -80,7 +80,7 @@ RT_RENDER_TIME_KERNELS = 2
 # Every symbol include/rt_amd.h declares.
 RT_AMD_SYMBOLS = [
     "rt_version", "rt_init", "rt_shutdown", "rt_last_error", "rt_bvh_build", "rt_bvh_build_ex", "rt_prim_bounds", "rt_scene_desc_check", "rt_scene_create",
-    "rt_scene_destroy", "rt_scene_get_bvh", "rt_trace_closest", "rt_trace_any", "rt_trace_closest_device",
+    "rt_scene_destroy", "rt_scene_get_bvh", "rt_trace_closest", "rt_trace_any", "rt_trace_closest_device", "rt_trace_closest_device_noalloc",
     "rt_render", "rt_render_device", "rt_tonemap_u8",
 ]
 
@@ -110,6 +110,7 @@ def load_rt_amd():
     lib.rt_trace_closest.argtypes = [vp, C.c_size_t, f32p, f32p, f32p, i32p, f32p, f32p]
     lib.rt_trace_any.argtypes = [vp, C.c_size_t, f32p, f32p, f32p, u8p]
     lib.rt_trace_closest_device.argtypes = [vp, C.c_size_t, vp, vp, C.c_int, C.c_int, C.POINTER(TraceStats)]
+    lib.rt_trace_closest_device_noalloc.argtypes = [vp, C.c_size_t, vp, vp, C.c_int, C.POINTER(TraceStats)]
     lib.rt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderOpts), f32p, C.POINTER(RenderStats)]
     lib.rt_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderOpts), C.POINTER(vp), C.POINTER(RenderStats)]
     lib.rt_tonemap_u8.argtypes = [f32p, C.c_int32, C.c_int32, C.c_int32, u8p]

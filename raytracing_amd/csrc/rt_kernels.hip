@@ -1431,11 +1431,22 @@ struct KernelTimer {
     }
 };
 
+// Scratch of rt_trace_closest_device_noalloc: [0, 16) the two work counters of the counting kernel, [256, ...) the spill area of
+// the per-lane traversal stacks.  Every GPU the library runs on holds its own copy until the process ends.  In host code the
+// name below is only a handle for hipGetSymbolAddress (rt_init); the address it yields, kept per context, is what host code
+// passes on.
+#define RT_NOALLOC_SPILL_BYTES ((size_t)32 << 20)
+#define RT_NOALLOC_SCRATCH_BYTES (RT_NOALLOC_SPILL_BYTES + 256)
+#define RT_NOALLOC_MAX_RAYS ((size_t)1 << 28)
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string error;
     int n_cu = 256;
+    unsigned char *scratch_ptr = nullptr;     // this device's copy of `scratch`
+    hipEvent_t ev_a = nullptr, ev_b = nullptr; // made once, so that the entry point that must not allocate can time its launches
 };
 static std::string g_init_error;
 static void set_error(rt_ctx *c, const std::string &s) { if (c) c->error = s; else g_init_error = s; }
@@ -1607,6 +1618,17 @@ int rt_init(int device, rt_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess) { g_init_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return -2; }
+    // this device's address of the static scratch array (the device was made current above)
+    void *sp = nullptr;
+    if ((e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch))) != hipSuccess || !sp) {
+        g_init_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return -2;
+    }
+    c->scratch_ptr = (unsigned char *)sp;
+    if ((e = hipEventCreate(&c->ev_a)) != hipSuccess || (e = hipEventCreate(&c->ev_b)) != hipSuccess) {
+        g_init_error = std::string("hipEventCreate: ") + hipGetErrorString(e);
+        if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+        (void)hipStreamDestroy(c->stream); delete c; return -2;
+    }
     *out = c;
     return 0;
 }
@@ -1614,6 +1636,8 @@ void rt_shutdown(rt_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
+    if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
     delete ctx;
 }
 
@@ -1826,17 +1850,18 @@ int rt_scene_get_bvh(rt_scene *this_, rt_bvh_node *nodes_out, int32_t *n_nodes_o
 extern "C++" {
 template <bool ANY, bool COUNT>
 static void launch_trace(rt_scene *this_, int grid, size_t n, const float *rays, int aos, int *prim, float *t, float *b1, float *b2, uint8_t *any_out,
-                         unsigned long long *work) {
+                         unsigned long long *work, int *spill = nullptr, bool allow_node_walk = true) {
     rt_ctx *ctx = this_->ctx;
-    if (env_int("RT_AMD_NODE_WALK", 0))      // knob: the one-node-per-step walk the frame kernels use
+    if (!spill) spill = (int *)this_->d_spill.p;      // the scene's own spill area, sized for the largest grid (rt_scene_create)
+    if (allow_node_walk && env_int("RT_AMD_NODE_WALK", 0))      // knob: the one-node-per-step walk the frame kernels use
         hipLaunchKernelGGL((k_trace_batch<ANY, COUNT>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
-                           (int *)this_->d_spill.p, work);
+                           spill, work);
     else if (!COUNT && this_->dev.quads)
         hipLaunchKernelGGL((k_trace_pairs<ANY, false, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
-                           (int *)this_->d_spill.p, work, tune_leaf_min());
+                           spill, work, tune_leaf_min());
     else
         hipLaunchKernelGGL((k_trace_pairs<ANY, COUNT, false>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
-                           (int *)this_->d_spill.p, work, tune_leaf_min());
+                           spill, work, tune_leaf_min());
 }
 }
 
@@ -1909,6 +1934,48 @@ int rt_trace_closest_device(rt_scene *this_, size_t n, const void *rays, void *h
     float ms = 0.f;
     HIP_OK(hipEventElapsedTime(&ms, ev.a, ev.b));
     if (stats) stats->seconds = (double)ms * 1e-3 / repeats;
+    return 0;
+}
+
+// rt_trace_closest_device for callers that cannot allocate: the spill area of the traversal stacks and the work counters live
+// in this device's copy of the static `scratch` array instead of buffers the library allocates.  The grid is cut down until its
+// lanes' stacks fit the spill area (32 MiB): at least 256 blocks for any tree rt_scene_create accepts.
+int rt_trace_closest_device_noalloc(rt_scene *this_, size_t n, const void *rays, void *hits, int count_work, rt_trace_stats *stats) {
+    if (!this_ || !rays || !hits || n == 0) return -1;
+    rt_ctx *ctx = this_->ctx;
+    if (n > RT_NOALLOC_MAX_RAYS) { set_error(ctx, "rt_trace_closest_device_noalloc: more than 2^28 rays in one call"); return -1; }
+    if (count_work && !stats) { set_error(ctx, "rt_trace_closest_device_noalloc: count_work needs a stats record to return the counts in"); return -1; }
+    if (!ctx->scratch_ptr) { set_error(ctx, "rt_trace_closest_device_noalloc: the context has no scratch address"); return -1; }
+    HIP_OK(hipSetDevice(ctx->device));
+    // stack entries per lane the kernels may spill: the counting kernel walks pair records (RT_MAX_STACK), the other one quad records
+    const int cap = std::max(RT_MAX_STACK, this_->dev.quads ? this_->dev.quad_stack_cap : 0);
+    const size_t per_block = (size_t)RT_BLOCK * (size_t)cap * 2 * sizeof(int);
+    const size_t fit = RT_NOALLOC_SPILL_BYTES / per_block;
+    if (fit < 1) { set_error(ctx, "rt_trace_closest_device_noalloc: the tree's traversal stack does not fit the static scratch"); return -1; }
+    int grid = (int)std::min<size_t>(std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)ctx->n_cu * trace_blocks_per_cu()), fit);
+    int *prim = (int *)hits; float *t = (float *)hits + n, *b1 = (float *)hits + 2 * n, *b2 = (float *)hits + 3 * n;
+    unsigned long long *work = (unsigned long long *)ctx->scratch_ptr;
+    int *spill = (int *)(ctx->scratch_ptr + 256);
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (count_work) {
+        HIP_OK(hipMemsetAsync(work, 0, 16, ctx->stream));        // the array keeps the last call's counts
+        launch_trace<false, true>(this_, grid, n, (const float *)rays, 0, prim, t, b1, b2, nullptr, work, spill, false);
+        HIP_OK(hipGetLastError());
+        unsigned long long w[2];
+        HIP_OK(hipMemcpyAsync(w, work, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+        stats->nodes_visited = w[0]; stats->prims_tested = w[1];
+    }
+    if (stats) HIP_OK(hipEventRecord(ctx->ev_a, ctx->stream));
+    launch_trace<false, false>(this_, grid, n, (const float *)rays, 0, prim, t, b1, b2, nullptr, nullptr, spill, false);
+    HIP_OK(hipGetLastError());
+    if (stats) {
+        HIP_OK(hipEventRecord(ctx->ev_b, ctx->stream));
+        HIP_OK(hipEventSynchronize(ctx->ev_b));
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b));
+        stats->seconds = (double)ms * 1e-3;
+    } else HIP_OK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
