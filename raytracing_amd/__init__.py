@@ -85,6 +85,10 @@ class HostScene:
             raise RuntimeError("rth_scene_camera failed")
         return cam
 
+    def texture_source(self, index):
+        """File the image texture `index` was decoded from ("" when there is none)."""
+        return host().rth_scene_texture_source(self._h, index).decode()
+
     def nodes(self):
         d = self.desc
         buf = C.string_at(d.bvh_nodes, d.n_nodes * 32)

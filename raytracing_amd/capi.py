@@ -124,6 +124,7 @@ def load_rt_host():
     lib.rth_last_error.restype = C.c_char_p
     lib.rth_scene_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int64]; lib.rth_scene_build.restype = vp
     lib.rth_scene_desc.argtypes = [vp]; lib.rth_scene_desc.restype = C.POINTER(SceneDesc)
+    lib.rth_scene_texture_source.argtypes = [vp, C.c_int]; lib.rth_scene_texture_source.restype = C.c_char_p
     lib.rth_scene_camera.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Camera)]
     lib.rth_scene_free.argtypes = [vp]; lib.rth_scene_free.restype = None
     lib.rth_register_image.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint8)]; lib.rth_register_image.restype = None

@@ -252,7 +252,7 @@ void RegisterImage(const std::string &name, int width, int height, const uint8_t
 
 std::shared_ptr<ImageData> LoadImageRGB(const std::string &filename) {
     std::string path = NormalizePath(filename);
-    Raw8 raw; const Raw8 *src = nullptr;
+    Raw8 raw; const Raw8 *src = nullptr; std::string from;
     auto it = Registry().find(BaseName(path));
     if (it != Registry().end()) src = &it->second;
     else {
@@ -264,11 +264,12 @@ std::shared_ptr<ImageData> LoadImageRGB(const std::string &filename) {
             std::ifstream f(t, std::ios::binary);
             if (!f) continue;
             std::vector<uint8_t> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-            if (DecodeImageRGB8(buf.data(), buf.size(), &raw.w, &raw.h, &raw.rgb)) { src = &raw; break; }
+            if (DecodeImageRGB8(buf.data(), buf.size(), &raw.w, &raw.h, &raw.rgb)) { src = &raw; from = t; break; }
         }
     }
     if (!src) return nullptr;
     auto img = std::make_shared<ImageData>();
+    img->source = from;
     img->width = src->w; img->height = src->h; img->rgb.resize(src->rgb.size());
     for (size_t i = 0; i < src->rgb.size(); ++i) img->rgb[i] = src->rgb[i] / 255.f;   // imageio.cpp:36-38
     return img;
@@ -279,6 +280,7 @@ std::shared_ptr<ImageData> ResampleToPow2(const std::shared_ptr<ImageData> &img)
     if (IsPow2(img->width) && IsPow2(img->height)) return img;
     int W = img->width, H = img->height, W2 = RoundUpPow2(W), H2 = RoundUpPow2(H);
     auto out = std::make_shared<ImageData>(); out->width = W2; out->height = H2; out->rgb.assign((size_t)W2 * H2 * 3, 0.f);
+    out->source = img->source;
     std::vector<RW> sw = ResampleWeights(W, W2);
     for (int t = 0; t < H; ++t)
         for (int s = 0; s < W2; ++s)
@@ -385,7 +387,7 @@ std::unique_ptr<FlatScene> FlattenScene(const Scene &scene) {
         auto it = texIndex.find(t);
         if (it != texIndex.end()) return it->second;
         rt_texture d; t->Describe(&d);
-        int id = (int)fs->textures.size(); fs->textures.push_back(d); texIndex[t] = id; return id;
+        int id = (int)fs->textures.size(); fs->textures.push_back(d); fs->texture_sources.push_back(t->Source()); texIndex[t] = id; return id;
     };
     for (size_t i = 0; i < agg->primitives.size(); ++i) {
         const GeometricPrimitive *gp = dynamic_cast<const GeometricPrimitive *>(agg->primitives[i].get());

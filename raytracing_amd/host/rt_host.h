@@ -218,6 +218,7 @@ class TextureBase {
 public:
     virtual ~TextureBase() {}
     virtual void Describe(rt_texture *out) const = 0;
+    virtual std::string Source() const { return ""; }
 };
 template <typename T> class Texture : public TextureBase {
 public:
@@ -239,7 +240,7 @@ public:
 
 // Decoded image: float RGB, row-major, after the reference's load conventions
 // (8-bit / 255, no gamma: imageio.cpp:19-45; Lanczos resample to powers of two: mipmap.h:70-121).
-struct ImageData { int width = 0, height = 0; std::vector<float> rgb; };
+struct ImageData { int width = 0, height = 0; std::vector<float> rgb; std::string source; /* file it was decoded from, if any */ };
 // 8-bit RGB pixels of a PNG (non-interlaced) or JPEG (baseline / progressive Huffman) held in memory.
 bool DecodeImageRGB8(const uint8_t *data, size_t size, int *width, int *height, std::vector<uint8_t> *rgb);
 bool DecodeJPEG(const uint8_t *data, size_t size, int *width, int *height, std::vector<uint8_t> *rgb);   // jpeg_decode.cpp
@@ -256,6 +257,7 @@ public:
     ImageTexture(std::unique_ptr<TextureMapping2D> mapping, const std::string &filename, bool doTrilinear, Float maxAniso,
                  ImageWrap wrapMode, Float scale, bool gamma);
     void Describe(rt_texture *out) const override;
+    std::string Source() const override { return image ? image->source : ""; }
 private:
     std::shared_ptr<ImageData> image;
     Float su = 1, sv = 1, du = 0, dv = 0;
@@ -423,6 +425,7 @@ struct FlatScene {
     std::vector<rt_light> lights;
     std::vector<rt_bvh_node> nodes;
     std::vector<std::shared_ptr<ImageData>> keepalive;
+    std::vector<std::string> texture_sources;   // per texture: the file an image texture came from, else ""
     void Bind();   // point desc at the vectors
 };
 

@@ -7,6 +7,7 @@
 //   "helmet"    DamagedHelmet()   :218-316
 //   "spheres2"  sphere1() plus a GlassMaterial sphere and an earth-textured sphere
 //               (the Lambertian / metal / dielectric + earthmap configuration)
+//   "cornell_metal", "spheres3"  test scenes for branches the shipped scenes never take (see BuildCornellMetal, BuildSpheres)
 //   "soup"      N random triangles in a 100^3 box (BVH traversal stress; no reference counterpart)
 #include "rt_host.h"
 
@@ -93,6 +94,59 @@ void BuildCornell(BuiltScene &bs, bool plastic = false) {
     bs.lookat = LookAt(Point3f(2.5f, 2.5f, 11.8f), Point3f(2.5f, 2.5f, 0.0f), Vector3f(0.0f, 1.0f, 0.0f));
 }
 
+// "cornell_metal": the Cornell box with the branches no shipped scene reaches.
+//   tall block   MetalMaterial exactly as the reference constructs (and never attaches) it, RayTracing.cpp:57-63:
+//                eta (0.18, 0.15, 0.81), k 0.11, roughness 0.2 on both axes, no remap             material.cpp:51-67, reflection.cpp:23-42
+//   short cube   MetalMaterial with anisotropic roughness 0.05 / 0.4 through RoughnessToAlpha       microfacet.h:74-78
+//   ceiling light, first triangle: wound the other way round (geometric normal up) in a mesh whose vertex normals point down,
+//                so Triangle::Sample turns the sampled normal to face them                          triangle.cpp:237-241
+//   ceiling light, second triangle: wound the other way round with reverseOrientation = true        triangle.cpp:242-243
+//   a small two-sided emitter standing in the room                                                  light.h:73-75
+void BuildCornellMetal(BuiltScene &bs) {
+    std::vector<std::shared_ptr<Primitive>> prims; std::vector<std::shared_ptr<Light>> lights;
+    std::shared_ptr<Material> mlight = Matte(Spectrum(1.0f, 1.0f, 1.0f));
+    {
+        const float y = 5 - 0.01; float len = 0.5;
+        Transform o2w = Translate(Vector3f(2.5f, 0.0f, 2.5f)) * Transform();
+        const Transform *po = bs.Keep(o2w), *pi = bs.Keep(Inverse(o2w));
+        int idx[3] = {0, 1, 2};
+        Point3f A[3] = {Point3f(-len, y, len), Point3f(len, y, len), Point3f(-len, y, -len)};      // Cross(p1 - p0, p2 - p0) points up
+        Normal3f NA[3] = {Normal3f(0.f, -1.f, 0.f), Normal3f(0.f, -1.f, 0.f), Normal3f(0.f, -1.f, 0.f)};
+        auto t0 = CreateTriangleMesh(po, pi, false, 1, idx, 3, A, nullptr, NA, nullptr, nullptr);
+        Point3f B[3] = {Point3f(len, y, len), Point3f(len, y, -len), Point3f(-len, y, -len)};        // up as well; reverseOrientation turns the sample's
+        auto t1 = CreateTriangleMesh(po, pi, true, 1, idx, 3, B, nullptr, nullptr, nullptr, nullptr);
+        for (auto &tri : {t0[0], t1[0]}) {
+            std::shared_ptr<AreaLight> area = make_shared<DiffuseAreaLight>(*po, Spectrum(20.f), 1, tri, false);
+            lights.push_back(area);
+            prims.push_back(make_shared<GeometricPrimitive>(tri, mlight, area));
+        }
+        // two-sided emitter: a vertical triangle in the plane x = 2.2
+        Transform o2 = Translate(Vector3f(2.2f, 3.2f, 3.4f)) * RotateY(25) * Transform();
+        const Transform *qo = bs.Keep(o2), *qi = bs.Keep(Inverse(o2));
+        Point3f Cc[3] = {Point3f(0.f, 0.f, -0.35f), Point3f(0.f, 0.f, 0.35f), Point3f(0.f, 0.6f, 0.f)};
+        auto t2 = CreateTriangleMesh(qo, qi, false, 1, idx, 3, Cc, nullptr, nullptr, nullptr, nullptr);
+        std::shared_ptr<AreaLight> area2 = make_shared<DiffuseAreaLight>(*qo, Spectrum(9.f, 7.f, 4.f), 1, t2[0], true);
+        lights.push_back(area2);
+        prims.push_back(make_shared<GeometricPrimitive>(t2[0], mlight, area2));
+    }
+    std::shared_ptr<Material> mirror = make_shared<MirrorMaterial>(Const(Spectrum(1.f)));
+    std::shared_ptr<Material> mgreen = Matte(Spectrum(.12f, .45f, .15f)), mred = Matte(Spectrum(.65f, .05f, .05f)), mwhite = Matte(Spectrum(.73f, .73f, .73f));
+    std::shared_ptr<Material> metal = make_shared<MetalMaterial>(Const(Spectrum(0.18f, 0.15f, 0.81f)), Const(Spectrum(0.11f, 0.11f, 0.11f)), ConstF(0.2f),
+                                                                 ConstF(0.2f), ConstF(0.2f), false);
+    std::shared_ptr<Material> brushed = make_shared<MetalMaterial>(Const(Spectrum(0.2f, 0.92f, 1.1f)), Const(Spectrum(3.9f, 2.45f, 2.14f)), ConstF(0.3f),
+                                                                   ConstF(0.05f), ConstF(0.4f), true);
+    Float L = 5;
+    auto room = BoxTriangles(bs, Transform(), 10, L, L, L);
+    for (int i = 0; i < 10; ++i) prims.push_back(make_shared<GeometricPrimitive>(room[i], i < 6 ? mwhite : (i < 8 ? mred : mgreen), nullptr));
+    Float h = 1.486f;
+    auto cube = BoxTriangles(bs, Translate(Vector3f(0.7f, 0.f, 2.8f)) * RotateY(18) * Transform(), 12, h, h, h);
+    for (int i = 0; i < 12; ++i) prims.push_back(make_shared<GeometricPrimitive>(cube[i], brushed, nullptr));
+    auto block = BoxTriangles(bs, Translate(Vector3f(2.7f, 0.f, 1.0f)) * RotateY(-15) * Transform(), 12, h, h, h * 2);
+    for (int i = 0; i < 12; ++i) prims.push_back(make_shared<GeometricPrimitive>(block[i], i < 10 ? metal : mirror, nullptr));
+    bs.scene = make_shared<Scene>(make_shared<BVHAccel>(prims), lights);
+    bs.lookat = LookAt(Point3f(2.5f, 2.5f, 11.8f), Point3f(2.5f, 2.5f, 0.0f), Vector3f(0.0f, 1.0f, 0.0f));
+}
+
 // rand()-driven helpers of the reference's entry file (RayTracing.cpp:30-44).  The reference
 // passes several rand() calls as arguments of one constructor call; the draws below are
 // sequenced last-argument-first, which is what g++ and MSVC do for such calls.
@@ -107,7 +161,9 @@ void AddSphere(BuiltScene &bs, std::vector<std::shared_ptr<Primitive>> &prims, c
     prims.push_back(make_shared<GeometricPrimitive>(make_shared<Sphere>(po, pi, false, r), m, nullptr));
 }
 
-void BuildSpheres(BuiltScene &bs, bool extended, const std::string &assets) {
+// variant 2 ("spheres3"): the extended scene plus a sphere whose texture is a 300 x 200 PNG (not powers of two: resampled to
+// 512 x 256 on load, mipmap.h:70-121) looked up through UVMapping2D(2, 3, 0.25, 0.5) (texture.cpp:5-13)
+void BuildSpheres(BuiltScene &bs, bool extended, const std::string &assets, bool oddTexture = false) {
     srand(1);   // glibc's default seed, so repeated builds in one process give the same layout
     std::vector<std::shared_ptr<Primitive>> prims;
     AddSphere(bs, prims, Vector3f(0.f, -1000.f, 0.f), 1000.0, Matte(Spectrum(0.5, 0.5, 0.5)));
@@ -136,6 +192,11 @@ void BuildSpheres(BuiltScene &bs, bool extended, const std::string &assets) {
     AddSphere(bs, prims, Vector3f(4, 1, 0), 1.0, make_shared<MirrorMaterial>(Const(Spectrum(0.7, 0.6, 0.5))));
     if (extended)
         AddSphere(bs, prims, Vector3f(0, 1, 0), 1.0, make_shared<GlassMaterial>(Const(Spectrum(1.f)), Const(Spectrum(1.f)), ConstF(1.5f)));
+    if (oddTexture) {
+        shared_ptr<Texture<Spectrum>> pat = make_shared<ImageTexture<RGBSpectrum, Spectrum>>(
+            make_unique<UVMapping2D>(2.f, 3.f, 0.25f, 0.5f), assets + "/pattern_300x200.png", false, 8.f, ImageWrap::Repeat, 1.f, false);
+        AddSphere(bs, prims, Vector3f(6.5f, 0.8f, 2.2f), 0.8, make_shared<MatteMaterial>(pat, ConstF(0.0f)));
+    }
     std::vector<std::shared_ptr<Light>> lights;
     bs.scene = make_shared<Scene>(make_shared<BVHAccel>(prims), lights);
     bs.lookat = LookAt(Point3f(13, 2, 3), Point3f(0.f, 0.f, 0.f), Vector3f(0.0f, 1.0f, 0.0f));
@@ -209,6 +270,8 @@ rth_scene *rth_scene_build(const char *name, const char *assets_dir, int64_t par
         else if (nm == "cornell_plastic") BuildCornell(h->b, true);
         else if (nm == "sphere1") BuildSpheres(h->b, false, assets);
         else if (nm == "spheres2") BuildSpheres(h->b, true, assets);
+        else if (nm == "spheres3") BuildSpheres(h->b, true, assets, true);
+        else if (nm == "cornell_metal") BuildCornellMetal(h->b);
         else if (nm == "helmet") BuildHelmet(h->b, assets);
         else if (nm == "helmet_glb") BuildHelmet(h->b, assets, "/DamagedHelmet/glTF-Binary/DamagedHelmet.glb");   // the same model as one binary container
         else if (nm == "soup") BuildSoup(h->b, param);
@@ -218,6 +281,11 @@ rth_scene *rth_scene_build(const char *name, const char *assets_dir, int64_t par
     return h;
 }
 const rt_scene_desc *rth_scene_desc(rth_scene *h) { return &h->b.flat->desc; }
+// File an image texture was loaded from ("" for constants, registered images and scenes without an object graph).
+const char *rth_scene_texture_source(rth_scene *h, int index) {
+    const std::vector<std::string> &src = h->b.flat->texture_sources;
+    return (index >= 0 && index < (int)src.size()) ? src[index].c_str() : "";
+}
 int rth_scene_camera(rth_scene *h, int width, int height, rt_camera *out) {
     Transform c2w = Inverse(h->b.lookat);
     std::unique_ptr<PerspectiveCamera> cam(CreatePerspectiveCamera(c2w, h->b.nearPlane, h->b.fov, width, height));

@@ -82,6 +82,17 @@ def make_rays(scene, osc, cam, n_each, seed):
     return np.ascontiguousarray(o, np.float32), np.ascontiguousarray(d, np.float32), np.ascontiguousarray(tm, np.float32)
 
 
+def normalise_nodes(raw_nodes):
+    """flattenBVHTree never writes a leaf's axis byte or any node's pad byte (bvh.cpp:229-245) and the node array is not cleared
+    when it is allocated, so those bytes hold whatever the allocator hands out (zeros in a fresh process, leftovers of the
+    texture resampling buffers in a scene that resamples one).  They carry no information: stored as zero."""
+    a = np.frombuffer(raw_nodes, dtype=np.uint8).copy().reshape(-1, 32)
+    leaf = (a[:, 28].astype(np.uint16) | (a[:, 29].astype(np.uint16) << 8)) > 0
+    a[leaf, 30] = 0
+    a[:, 31] = 0
+    return a.reshape(-1)
+
+
 def golden_for_scene(name, n_rays, img_specs, probe_n=512):
     print("==", name)
     scene = ra.HostScene(name)
@@ -93,7 +104,7 @@ def golden_for_scene(name, n_rays, img_specs, probe_n=512):
     run("bvh", sbin, out)
     raw = open(out, "rb").read()
     nn = struct.unpack("<i", raw[:4])[0]
-    nodes = np.frombuffer(raw[4:4 + 32 * nn], dtype=np.uint8).copy()
+    nodes = normalise_nodes(raw[4:4 + 32 * nn])
     order = np.frombuffer(raw[4 + 32 * nn:], dtype=np.int32).copy()
     np.savez_compressed(os.path.join(GOLD, "ref_bvh_%s.npz" % name), nodes=nodes, order=order, n_nodes=nn)
     # --- ray batches
@@ -143,7 +154,7 @@ def golden_bvh_variants():
             subprocess.run([DRIVER, "bvh", sbin, path], check=True, env=env)
             raw = open(path, "rb").read()
             nn = struct.unpack("<i", raw[:4])[0]
-            out[tag + "_nodes"] = np.frombuffer(raw[4:4 + 32 * nn], dtype=np.uint8).copy()
+            out[tag + "_nodes"] = normalise_nodes(raw[4:4 + 32 * nn])
             out[tag + "_order"] = np.frombuffer(raw[4 + 32 * nn:], dtype=np.int32).copy()
             out[tag + "_args"] = np.array([maxp, method], np.int32)
             print("  ", name, tag, nn, "nodes")
@@ -209,6 +220,12 @@ if __name__ == "__main__":
         golden_for_scene("cornell", 4096, [(64, 64, 4, 4, [A, B]), (100, 100, 16, 16, [A, B])])
     if not only or "cornell_plastic" in only:      # the short cube carries a PlasticMaterial (two-lobe BSDF, material.cpp:32-49)
         golden_for_scene("cornell_plastic", 2048, [(100, 100, 16, 16, [A, B])])
+    # MetalMaterial (conductor Fresnel, anisotropic roughness, remap), a light with vertex normals, one with reverseOrientation, a two-sided one
+    if not only or "cornell_metal" in only:
+        golden_for_scene("cornell_metal", 2048, [(100, 100, 16, 16, [A, B])])
+    # a 300 x 200 texture (resampled to powers of two by the reference itself) behind UVMapping2D(2, 3, 0.25, 0.5)
+    if not only or "spheres3" in only:
+        golden_for_scene("spheres3", 2048, [(96, 96, 8, 8, [A, B])])
     if not only or "sphere1" in only:
         golden_for_scene("sphere1", 4096, [(64, 64, 4, 4, [A, B])])
     if not only or "spheres2" in only:

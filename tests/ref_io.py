@@ -11,6 +11,8 @@ CAMERAS = {   # eye, look, up of the reference's scene functions (RayTracing.cpp
     "cornell_plastic": ((2.5, 2.5, 11.8), (2.5, 2.5, 0.0), (0, 1, 0)),
     "sphere1": ((13, 2, 3), (0, 0, 0), (0, 1, 0)),
     "spheres2": ((13, 2, 3), (0, 0, 0), (0, 1, 0)),
+    "spheres3": ((13, 2, 3), (0, 0, 0), (0, 1, 0)),
+    "cornell_metal": ((2.5, 2.5, 11.8), (2.5, 2.5, 0.0), (0, 1, 0)),
     "helmet": ((3.5, 3.2, 1.5), (2.0, 2.3, 2.8), (0, 1, 0)),
 }
 
@@ -55,7 +57,12 @@ def dump_scene(scene, path, tmp):
         out.append(struct.pack("<7i", m.kind, *list(m.tex), m.remap_roughness, 0))
     for i in range(d.n_textures):
         t = d.textures[i]
-        png = texture_png(scene.name, t, i, tmp).encode() if t.kind == 1 else b""
+        png = b""
+        if t.kind == 1:
+            # a PNG source goes to the reference as it is (the reference then does its own resampling of images that are not
+            # powers of two, mipmap.h:70-121); anything else as a PNG of the texels, which must then be unresampled 8-bit data
+            src = scene.texture_source(i) if hasattr(scene, "texture_source") else ""
+            png = src.encode() if src.lower().endswith(".png") and os.path.exists(src) else texture_png(scene.name, t, i, tmp).encode()
         out.append(struct.pack("<3i3f4fi", t.kind, t.width, t.height, *list(t.value), t.su, t.sv, t.du, t.dv, len(png)) + png)
     for i in range(d.n_lights):
         L = d.lights[i]

@@ -10,7 +10,7 @@ import pytest
 import raytracing_amd as ra
 
 pytestmark = pytest.mark.gpu
-SCENES = ["cornell", "cornell_plastic", "sphere1", "spheres2", "helmet"]
+SCENES = ["cornell", "cornell_plastic", "cornell_metal", "sphere1", "spheres2", "spheres3", "helmet"]
 
 
 def _rel_close(img, ref, tol):
@@ -194,7 +194,8 @@ def test_trace_edge_cases(device_scene):
     assert prim[0] == -1
 
 
-@pytest.mark.parametrize("name,w,sx", [("cornell", 96, 4), ("cornell_plastic", 96, 4), ("sphere1", 96, 4), ("spheres2", 96, 4), ("helmet", 96, 4)])
+@pytest.mark.parametrize("name,w,sx", [("cornell", 96, 4), ("cornell_plastic", 96, 4), ("cornell_metal", 96, 4), ("sphere1", 96, 4), ("spheres2", 96, 4),
+                                       ("spheres3", 96, 4), ("helmet", 96, 4)])
 def test_render_matches_oracle_per_pixel(name, w, sx, device_scene, oracle_scene, host_scene):
     """Same sampler on both sides: identical ray counts (up to a handful of paths whose branch flips on a last-bit libm
     difference) and per-pixel sums equal within 2e-3 relative for all but a few such pixels."""
@@ -210,7 +211,8 @@ def test_render_matches_oracle_per_pixel(name, w, sx, device_scene, oracle_scene
     assert np.all(np.abs(img.mean(axis=(0, 1)) / ref.mean(axis=(0, 1)) - 1) < 2e-3)
 
 
-@pytest.mark.parametrize("name,w,spp", [("cornell", 100, 256), ("cornell_plastic", 100, 256), ("spheres2", 96, 64), ("helmet", 96, 64), ("sphere1", 64, 16)])
+@pytest.mark.parametrize("name,w,spp", [("cornell", 100, 256), ("cornell_plastic", 100, 256), ("cornell_metal", 100, 256), ("spheres2", 96, 64), ("spheres3", 96, 64),
+                                        ("helmet", 96, 64), ("sphere1", 64, 16)])
 def test_render_within_reference_noise_floor(name, w, spp, device_scene, host_scene, gold_dir):
     """Against images rendered by the reference's PathIntegrator::Li_re with its own sampler: per-channel mean within
     0.5 % and RMSE (vs the mean of the reference's two seeds) below the reference's own seed-A-vs-seed-B RMSE."""
@@ -302,7 +304,7 @@ def test_headline_frame_against_reference_and_shipped_image(device_scene, host_s
     assert np.all(np.abs(ratio - 1) < 0.03), ratio
 
 
-@pytest.mark.parametrize("name,w", [("cornell", 200), ("cornell_plastic", 120), ("helmet", 160), ("spheres2", 160)])
+@pytest.mark.parametrize("name,w", [("cornell", 200), ("cornell_plastic", 120), ("cornell_metal", 120), ("helmet", 160), ("spheres2", 160)])
 def test_frame_walks_give_identical_images(name, w, device_scene, host_scene, monkeypatch):
     """The frame kernels have three walks (round-based over pair/quad records, persistent lanes, round-based over plain
     nodes) and several ways of dividing and fusing the work.  Traversal is bit-exact in all of them and every sample is a pure
@@ -341,6 +343,9 @@ def test_scene_create_rejects_inconsistent_descriptions(host_scene, gpu_ctx):
         setattr(d, field, C.cast(arr, C.POINTER(C.c_int32)))
         with pytest.raises(RuntimeError):
             ra.DeviceScene(gpu_ctx, C.pointer(d))
+        d.bvh_nodes = None; d.prim_order = None; d.n_nodes = 0     # the library would build the tree itself: refused before it reads a bound
+        with pytest.raises(RuntimeError):
+            ra.DeviceScene(gpu_ctx, C.pointer(d))
     d = type(hs.desc).from_buffer_copy(hs.desc)
     nodes = (ra.capi.BvhNode * d.n_nodes)()
     C.memmove(nodes, hs.desc.bvh_nodes, 32 * d.n_nodes)
@@ -368,3 +373,17 @@ def test_drop_in_render_through_path_integrator(host_scene, oracle_scene, tmp_pa
     assert _rel_close(img, ref, 2e-3).mean() > 0.995
     u8 = np.asarray(Image.open(png).convert("RGB"))
     assert np.array_equal(u8, ra.tonemap_u8(img, 16))
+
+
+def test_kernel_class_times_add_up(device_scene, host_scene):
+    """RT_RENDER_TIME_KERNELS: the per-class times are filled, add up to the total within the gaps between launches, and the image is
+    the one rendered without the flag; without it the four fields stay zero."""
+    ds = device_scene("cornell")
+    cam = host_scene("cornell").camera(256, 256)
+    base, st0 = ds.render(cam, ra.make_opts(4, 4))
+    assert st0.seconds_trace == 0 and st0.seconds_shade == 0 and st0.seconds_shadow == 0 and st0.seconds_other == 0 and st0.seconds_total > 0
+    img, st = ds.render(cam, ra.make_opts(4, 4, flags=ra.capi.RT_RENDER_TIME_KERNELS))
+    assert np.array_equal(img, base)
+    parts = st.seconds_trace + st.seconds_shade + st.seconds_shadow + st.seconds_other
+    assert st.seconds_trace > 0 and st.seconds_shade > 0 and st.seconds_other > 0
+    assert 0.5 * st.seconds_total < parts <= st.seconds_total * 1.001

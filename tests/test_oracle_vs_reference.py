@@ -12,7 +12,10 @@ import raytracing_amd as ra
 import oracle_lib as ol
 from raytracing_amd import capi
 
-SCENES = ["cornell", "cornell_plastic", "sphere1", "spheres2", "helmet"]
+# cornell_metal: MetalMaterial (conductor Fresnel; isotropic without remap and anisotropic with it), a light triangle with vertex
+# normals, one with reverseOrientation, a two-sided one.  spheres3: a 300 x 200 texture the reference resamples to powers of two
+# itself, looked up through a scaled and shifted UVMapping2D.
+SCENES = ["cornell", "cornell_plastic", "cornell_metal", "sphere1", "spheres2", "spheres3", "helmet"]
 
 
 @pytest.mark.parametrize("name", SCENES)
@@ -97,3 +100,25 @@ def test_philox_sampler_agrees_statistically_with_reference_sampler(host_scene, 
     rmse = np.sqrt(((img - best) ** 2).mean(axis=(0, 1)))
     assert np.all(np.abs(img.mean(axis=(0, 1)) / best.mean(axis=(0, 1)) - 1) < 0.005)
     assert np.all(rmse < floor), (rmse, floor)
+
+
+def test_new_scenes_reach_the_branches_they_were_built_for(host_scene, oracle_scene, gold_dir):
+    """The goldens above only pin what their probes and paths touch; make sure they touch the metal lobes of both blocks, the odd
+    texture through its mapping, and all three kinds of light."""
+    g = np.load(os.path.join(gold_dir, "ref_probe_cornell_metal.npz"))
+    hs = host_scene("cornell_metal"); d = hs.desc
+    prim = g["out"][:, 0].astype(int)
+    kinds = {d.materials[d.prim_material[p]].kind for p in prim if p >= 0}
+    assert 3 in kinds                                                        # RT_MAT_METAL
+    metal_mats = {d.prim_material[p] for p in prim if p >= 0 and d.materials[d.prim_material[p]].kind == 3}
+    assert len(metal_mats) == 2                                              # the isotropic and the anisotropic / remapped one
+    glossy = g["out"][:, 25].astype(int) == 9                                # BSDF_REFLECTION | BSDF_GLOSSY sampled
+    assert glossy.sum() > 20 and (g["out"][glossy, 24] > 0).all()
+    assert [(d.lights[i].two_sided, d.lights[i].flip_normal) for i in range(3)] == [(0, 0), (0, 1), (1, 0)] and bool(d.tri_has_n[d.prim_geom[0]])
+    g = np.load(os.path.join(gold_dir, "ref_probe_spheres3.npz"))
+    hs = host_scene("spheres3"); d = hs.desc
+    odd = [i for i in range(d.n_textures) if d.textures[i].kind == 1 and (d.textures[i].width, d.textures[i].height) == (512, 256)]
+    assert len(odd) == 1 and (d.textures[odd[0]].su, d.textures[odd[0]].sv, d.textures[odd[0]].du, d.textures[odd[0]].dv) == (2.0, 3.0, 0.25, 0.5)
+    mats = [m for m in range(d.n_materials) if d.materials[m].tex[0] == odd[0]]
+    hit = [p for p in g["out"][:, 0].astype(int) if p >= 0 and d.prim_material[p] in mats]
+    assert len(hit) >= 3, "no probe lands on the sphere with the 300 x 200 texture"
