@@ -366,7 +366,9 @@ __device__ __forceinline__ F3 cosine_sample_hemisphere(float u0, float u1) {
         float theta, r;
         if (fabsf(ox) > fabsf(oy)) { r = ox; theta = RT_PI_OVER_4 * (oy / ox); }
         else { r = oy; theta = RT_PI_OVER_2 - RT_PI_OVER_4 * (ox / oy); }
-        dx = r * cosf(theta); dy = r * sinf(theta);
+        float sn, cs;
+        sincosf(theta, &sn, &cs);            // one argument reduction for both
+        dx = r * cs; dy = r * sn;
     }
     float z = sqrtf(fmaxf(0.f, 1 - dx * dx - dy * dy));
     return f3(dx, dy, z);
@@ -434,7 +436,9 @@ struct TRDist {
         if (cosTheta > .9999) {
             float r = sqrtf(U1 / (1 - U1));
             float phi = (float)(6.28318530718 * U2);
-            slope_x = r * cosf(phi); slope_y = r * sinf(phi);
+            float sn, cs;
+            sincosf(phi, &sn, &cs);
+            slope_x = r * cs; slope_y = r * sn;
         } else {
             float sinTheta = sqrtf(fmaxf(0.f, 1.f - cosTheta * cosTheta));
             float tanTheta = sinTheta / cosTheta;

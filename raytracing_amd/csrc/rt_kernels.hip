@@ -1172,6 +1172,75 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, Sh
     }
 }
 
+// k_shadow for scenes that live in LDS, with the carry-over of k_extend_carry: any-hit walks end after very different numbers of
+// steps (first hit ends the ray), so a wave that runs 64 shadow rays to completion spends most of its time with a handful of
+// lanes.  Here a lane whose ray is finished after RT_CARRY_ROUNDS rounds adds the unoccluded light to its path's radiance slot and
+// takes the next shadow ray of the wave's chunks.  Results are those of k_shadow bit for bit: the same walk, and each path's slot is
+// touched once per bounce by exactly one lane.
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow_carry(DevScene sc, int bounce, ShadowQueue sq, uint32_t segcap, float4 *lbuf, BounceCounts *counts,
+                                                            BounceStats *stats) {
+    __shared__ int s_stack[2 * RT_FRAME_RING * RT_BLOCK];
+    __shared__ float4 s_nodes[2 * RT_LDS_SCENE_NODES], s_slots[3 * RT_LDS_SCENE_SLOTS];
+    stage_pairs_lds(sc, s_nodes);
+    for (int i = threadIdx.x; i < 3 * sc.n_slots; i += RT_BLOCK) s_slots[i] = sc.slots[i];
+    PairStackT<RT_FRAME_RING, false> pst; pst.lds_i = &s_stack[threadIdx.x]; pst.lds_t = (float *)&s_stack[RT_FRAME_RING * RT_BLOCK + threadIdx.x]; pst.reset();
+    __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE];
+    BounceCounts *bc = counts + bounce;
+    const uint32_t total = segment_prefix(bc->shadow, s_prefix, s_wave);
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_shadow = total;
+    const uint32_t n_waves = gridDim.x * (RT_BLOCK / RT_WAVE), gwave = blockIdx.x * (RT_BLOCK / RT_WAVE) + threadIdx.x / RT_WAVE;
+    const uint32_t n_chunks = (total + RT_WAVE - 1) / RT_WAVE;
+    const uint32_t w_hi = (gwave < n_chunks ? (n_chunks - gwave + n_waves - 1) / n_waves : 0) * RT_WAVE;   // this wave's positions: logical [0, w_hi)
+    uint32_t w_next = 0, seg = 0;
+    const int rounds = n_chunks <= n_waves ? 1 << 20 : RT_CARRY_ROUNDS;
+    LaneTrav L = {};
+    L.mode = RT_LANE_DONE; L.hitSlot = -1;
+    bool busy = false;
+    uint32_t cur_i = 0, dummy = 0;
+    while (true) {
+        // ---- hand in finished rays: an unoccluded ray delivers its light (light.cpp:19-21, integrator.cpp:97-98)
+        if (busy && L.mode == RT_LANE_DONE) {
+            if (!L.found) {
+                const uint32_t id = sq.id[cur_i];
+                float4 Lr = lbuf[id];
+                Lr.x += sq.cr[cur_i]; Lr.y += sq.cg[cur_i]; Lr.z += sq.cb[cur_i];
+                lbuf[id] = Lr;
+            }
+            busy = false;
+        }
+        // ---- take the next rays of the wave's chunks
+        const uint64_t im = __ballot(!busy);
+        const uint32_t left = w_hi - w_next, nidle = (uint32_t)__popcll(im), take = nidle < left ? nidle : left;
+        const uint32_t ln = w_next + prefix_in_mask(im);                  // logical position -> queue position
+        const uint32_t g = ((ln / RT_WAVE) * n_waves + gwave) * RT_WAVE + (ln & (RT_WAVE - 1));
+        if (!busy && prefix_in_mask(im) < take && g < total) {
+            while (g >= s_prefix[seg + 1]) seg++;
+            cur_i = seg * segcap + (g - s_prefix[seg]);
+            F3 o = f3(sq.ox[cur_i], sq.oy[cur_i], sq.oz[cur_i]), d = f3(sq.dx[cur_i], sq.dy[cur_i], sq.dz[cur_i]);
+            bool have = lane_begin<false>(sc, L, pst, o, d, 1.f - 0.0001f, dummy);     // tMax = 1 - ShadowEpsilon (interaction.h:27-32)
+            lane_enter(sc, L, sc.root_info, have);
+            busy = true;
+        }
+        w_next += take;
+        if (__ballot(busy) == 0) break;
+#pragma unroll 1
+        for (int k = 0; k < rounds; ++k) {
+            while (L.mode == RT_LANE_WALK) {
+                uint32_t info; bool hv;
+                if (L.plain) lane_walk<false, true, RT_LDS_SCENE_NODES / 2>(s_nodes, L, pst, dummy, info, hv);
+                else lane_walk<false, false, RT_LDS_SCENE_NODES / 2>(s_nodes, L, pst, dummy, info, hv);
+                lane_enter(sc, L, info, hv);
+            }
+            if (L.mode == RT_LANE_LEAF) {
+                LeafOut r = lane_leaf<true, false>(sc, s_slots, L, pst, dummy);
+                L.found = r.found;
+                lane_enter(sc, L, r.info, r.have);
+            }
+            if (__ballot(L.mode != RT_LANE_DONE) == 0) break;
+        }
+    }
+}
+
 // ------------------------------------------------ persistent-lane frame tracing --
 // k_extend / k_shadow above give every lane one ray per round and the wave waits for its slowest lane: fine while rays
 // take similar numbers of steps, wasteful on deep trees with incoherent rays.  The kernels below walk the same queues with
@@ -2116,10 +2185,14 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     const int carry_from = env_int("RT_AMD_CARRY_FROM", 1);
     // shadow rays traced inside the shading kernels: scenes whose tree and tables both sit in LDS
     // (only while five blocks of the fused kernel still share a CU's 160 KB of LDS: 25.6 KB static + the scene's tables <= 32 KB)
-    const bool fuse_shadow = lds_scene && round_pairs && !frame_old && shade_tables_in_lds(this_->dev) && shade_lds_bytes(this_->dev) <= 6400 &&
-                             env_int("RT_AMD_FUSE_SHADOW", 1) != 0;
+    const bool all_in_lds = lds_scene && round_pairs && !frame_old && shade_tables_in_lds(this_->dev) && shade_lds_bytes(this_->dev) <= 6400;
+    // knob: shadow rays of LDS scenes through the shadow queue to k_shadow_carry (lanes refill as their any-hit walks end) instead of
+    // inside the shading kernel, where a wave runs its 64 shadow rays to completion.  Measured on the Cornell frame: shading alone
+    // 128 ms + k_shadow_carry 93 ms (round-based k_shadow: 106 ms) against 210 ms for the fused kernel, so fusing stays the default
+    const int shadow_carry_from = (lds_scene && round_pairs && !frame_old) ? env_int("RT_AMD_SHADOW_CARRY_FROM", 1 << 30) : 1 << 30;
+    const bool fuse_shadow = all_in_lds && shadow_carry_from > o->max_depth && env_int("RT_AMD_FUSE_SHADOW", 1) != 0;
     // the late, near-empty bounces of LDS scenes in one launch (k_finish)
-    const bool use_finish = (fuse_shadow || (!lds_scene && round_quads && !frame_old)) && env_int("RT_AMD_FINISH", 1) != 0;
+    const bool use_finish = (all_in_lds || (!lds_scene && round_quads && !frame_old)) && env_int("RT_AMD_FINISH", 1) != 0;
     const int finish_chunks = env_int("RT_AMD_FINISH_CHUNKS", 2);
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
         int cur = std::min(spb, o->sample_end - s0);
@@ -2172,7 +2245,9 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                 tm.mark(RT_TIME_SHADE);
                 if (this_->dev.n_lights > 0 && !fuse_shadow) {
                     if (frame_old || b < round_bounces) {
-                        if (lds_scene)
+                        if (b >= shadow_carry_from)
+                            hipLaunchKernelGGL(k_shadow_carry, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats);
+                        else if (lds_scene)
                             hipLaunchKernelGGL(k_shadow<true>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
                                                (int *)this_->d_spill.p, round_pairs | rr_shadow);
                         else

@@ -98,10 +98,12 @@ __device__ __forceinline__ bool slab_fast(float bminx, float bminy, float bminz,
     float x0 = (bminx - o.x) * invDir.x, x1 = (bmaxx - o.x) * invDir.x;
     float y0 = (bminy - o.y) * invDir.y, y1 = (bmaxy - o.y) * invDir.y;
     float z0 = (bminz - o.z) * invDir.z, z1 = (bmaxz - o.z) * invDir.z;
-    float nx = fminf(x0, x1), fx = fmaxf(x0, x1) * widen;
-    float ny = fminf(y0, y1), fy = fmaxf(y0, y1) * widen;
-    float nz = fminf(z0, z1), fz = fmaxf(z0, z1) * widen;
-    float tMin = fmaxf(fmaxf(nx, ny), nz), tMax = fminf(fminf(fx, fy), fz);
+    // the far planes are widened after the minimum is taken: x -> fl(x * widen) is monotonic, so min(fl(a w), fl(b w), fl(c w)) is
+    // fl(min(a, b, c) w), bit for bit, and two multiplications are saved
+    float nx = fminf(x0, x1), fx = fmaxf(x0, x1);
+    float ny = fminf(y0, y1), fy = fmaxf(y0, y1);
+    float nz = fminf(z0, z1), fz = fmaxf(z0, z1);
+    float tMin = fmaxf(fmaxf(nx, ny), nz), tMax = fminf(fminf(fx, fy), fz) * widen;
     tMinOut = tMin;
     return tMin <= tMax && tMax > 0;
 }

@@ -11,9 +11,12 @@ cam = s.camera(w, w)
 if reps > 1:
     ds.render_device(cam, ra.make_opts(sx, sy, pool_paths=pool))
 best = None
+flags = ra.capi.RT_RENDER_TIME_KERNELS if os.environ.get("PROF_TIME") else 0
 for _ in range(reps):
-    _, st = ds.render_device(cam, ra.make_opts(sx, sy, pool_paths=pool))
+    _, st = ds.render_device(cam, ra.make_opts(sx, sy, pool_paths=pool, flags=flags))
     if best is None or st.seconds_total < best.seconds_total:
         best = st
 st = best
 print("samples", st.samples, "closest", st.rays_closest, "shadow", st.rays_shadow, "dev_s", st.seconds_total, "Msamples/s", st.samples / st.seconds_total / 1e6)
+if flags:
+    print("  per class [s]: trace %.4f shade %.4f shadow %.4f other %.4f" % (st.seconds_trace, st.seconds_shade, st.seconds_shadow, st.seconds_other))
