@@ -259,9 +259,33 @@ int rt_render(rt_scene *scene, const rt_camera *cam, const rt_render_opts *opts,
 int rt_render_device(rt_scene *scene, const rt_camera *cam, const rt_render_opts *opts,
                      void **out_device_sum, rt_render_stats *stats);
 
+/* ---- every GPU of the node from one process ----
+ * The reference renders a frame with one call, Integrator::Render (include/core/integrator.h:17-21), on a pool of threads
+ * that share the pixels (integrator.cpp:378-405).  Here the samples of every pixel are shared out instead: device k of n
+ * renders samples rt_split_samples(k, n) of every pixel on its own copy of the scene, driven by its own host thread, and the
+ * per-device sum buffers are merged onto devices[0] once per frame (peer copies over xGMI + an add, in device order).  A device
+ * may be listed more than once (two contexts on one GPU). */
+typedef struct rt_multi rt_multi;
+int rt_device_count(void);                                  /* HIP devices visible to the process (0 without a GPU) */
+/* The share of [0, total) that rank `rank` of `world` renders: contiguous, exhaustive, sizes differ by at most one. Host only. */
+int rt_split_samples(int32_t total, int32_t rank, int32_t world, int32_t *begin, int32_t *end);
+int rt_multi_create(const int32_t *devices, int32_t n_devices, const rt_scene_desc *desc, rt_multi **out);
+void rt_multi_destroy(rt_multi *m);
+const char *rt_multi_last_error(rt_multi *m);               /* m may be NULL for rt_multi_create failures */
+/* rt_render over all devices of m: out_sum_rgb as in rt_render; stats_per_device (n_devices records) and stats_total
+ * (counts summed, seconds_total = slowest device) may be NULL. */
+int rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_opts *opts, float *out_sum_rgb,
+                    rt_render_stats *stats_per_device, rt_render_stats *stats_total);
+
 /* mean -> NaN->0 -> sqrt -> 256*clamp(.,0,0.999) -> u8 — write_color
  * (include/core/integrator.cpp:289-308).  Host, needs no GPU. */
 int rt_tonemap_u8(const float *sum_rgb, int32_t width, int32_t height, int32_t spp, uint8_t *out_rgb);
+
+/* The other output format of the reference: the P3 (text) PPM its first-generation entry file writes — header
+ * (RayTracing/main.cpp:106) and one line per pixel through that file's write_color (RayTracing/main.cpp:28-48, also
+ * include/color.h), whose arithmetic differs from integrator.cpp's in where the division by spp happens.  Rows as stored
+ * (row 0 first).  Host, needs no GPU.  0 = ok, -2 = the file cannot be written. */
+int rt_write_ppm(const char *path, const float *sum_rgb, int32_t width, int32_t height, int32_t spp);
 
 #ifdef __cplusplus
 }

@@ -154,6 +154,13 @@ def tonemap_u8(sum_rgb, spp):
     return out
 
 
+def write_ppm(path, sum_rgb, spp):
+    sum_rgb = np.ascontiguousarray(sum_rgb, np.float32)
+    h, w = sum_rgb.shape[:2]
+    if rt().rt_write_ppm(str(path).encode(), capi.fptr(sum_rgb), w, h, spp) != 0:
+        raise RuntimeError("rt_write_ppm failed")
+
+
 def make_opts(sx, sy, begin=0, end=None, max_depth=50, seed=(0x243F6A88, 0x85A308D3), pool_paths=0, flags=0):
     o = RenderOpts()
     o.strata_x, o.strata_y = sx, sy
@@ -250,3 +257,33 @@ class DeviceScene:
         if self._p:
             rt().rt_scene_destroy(self._p)
             self._p = C.c_void_p()
+
+
+class MultiScene:
+    """rt_multi: one context and scene copy per listed device (a device may appear twice), samples of every pixel shared out."""
+
+    def __init__(self, devices, desc_ptr):
+        self.devices = list(devices)
+        arr = (C.c_int32 * len(self.devices))(*self.devices)
+        self._p = C.c_void_p()
+        if rt().rt_multi_create(arr, len(self.devices), desc_ptr, C.byref(self._p)) != 0:
+            raise RuntimeError(rt().rt_multi_last_error(None).decode())
+
+    def render(self, cam, opts):
+        out = np.zeros((cam.height, cam.width, 3), np.float32)
+        per = (RenderStats * len(self.devices))(); tot = RenderStats()
+        if rt().rt_multi_render(self._p, C.byref(cam), C.byref(opts), capi.fptr(out), per, C.byref(tot)) != 0:
+            raise RuntimeError(rt().rt_multi_last_error(self._p).decode())
+        return out, list(per), tot
+
+    def close(self):
+        if self._p:
+            rt().rt_multi_destroy(self._p)
+            self._p = C.c_void_p()
+
+
+def split_samples(total, rank, world):
+    b = C.c_int32(); e = C.c_int32()
+    if rt().rt_split_samples(total, rank, world, C.byref(b), C.byref(e)) != 0:
+        raise ValueError("bad rank/world")
+    return b.value, e.value

@@ -82,6 +82,7 @@ RT_AMD_SYMBOLS = [
     "rt_version", "rt_init", "rt_shutdown", "rt_last_error", "rt_bvh_build", "rt_bvh_build_ex", "rt_prim_bounds", "rt_scene_desc_check", "rt_scene_create",
     "rt_scene_destroy", "rt_scene_get_bvh", "rt_trace_closest", "rt_trace_any", "rt_trace_closest_device", "rt_trace_closest_device_noalloc",
     "rt_render", "rt_render_device", "rt_tonemap_u8",
+    "rt_device_count", "rt_split_samples", "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error", "rt_multi_render", "rt_write_ppm",
 ]
 
 
@@ -113,6 +114,12 @@ def load_rt_amd():
     lib.rt_trace_closest_device_noalloc.argtypes = [vp, C.c_size_t, vp, vp, C.c_int, C.POINTER(TraceStats)]
     lib.rt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderOpts), f32p, C.POINTER(RenderStats)]
     lib.rt_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderOpts), C.POINTER(vp), C.POINTER(RenderStats)]
+    lib.rt_split_samples.argtypes = [C.c_int32, C.c_int32, C.c_int32, i32p, i32p]
+    lib.rt_multi_create.argtypes = [i32p, C.c_int32, C.POINTER(SceneDesc), C.POINTER(vp)]
+    lib.rt_multi_destroy.argtypes = [vp]; lib.rt_multi_destroy.restype = None
+    lib.rt_multi_last_error.argtypes = [vp]; lib.rt_multi_last_error.restype = C.c_char_p
+    lib.rt_multi_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderOpts), f32p, C.POINTER(RenderStats), C.POINTER(RenderStats)]
+    lib.rt_write_ppm.argtypes = [C.c_char_p, f32p, C.c_int32, C.c_int32, C.c_int32]
     lib.rt_tonemap_u8.argtypes = [f32p, C.c_int32, C.c_int32, C.c_int32, u8p]
     return lib
 

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -196,6 +197,31 @@ int rt_tonemap_u8(const float *sum_rgb, int32_t width, int32_t height, int32_t s
         out_rgb[i] = (uint8_t)(int)(256 * c);
     }
     return 0;
+}
+
+// The P3 text output of the reference's first-generation entry file: header "P3\nW H\n255\n" (main.cpp:106), then one
+// "r g b\n" line per pixel through its write_color (main.cpp:28-48): NaN -> 0, scale = 1.0 / spp as a double,
+// sqrt(scale * c) in double stored back into the float channel, 256 * clamp(c, 0, 0.999) with the clamp in double, truncated.
+int rt_write_ppm(const char *path, const float *sum_rgb, int32_t width, int32_t height, int32_t spp) {
+    if (!path || !sum_rgb || width <= 0 || height <= 0 || spp <= 0) return -1;
+    FILE *f = fopen(path, "wb");
+    if (!f) return -2;
+    fprintf(f, "P3\n%d %d\n255\n", width, height);
+    const double scale = 1.0 / spp;
+    size_t n = (size_t)width * height;
+    for (size_t p = 0; p < n; ++p) {
+        int v[3];
+        for (int c = 0; c < 3; ++c) {
+            float r = sum_rgb[3 * p + c];
+            if (r != r) r = 0.0;
+            r = (float)std::sqrt(scale * r);
+            double cl = r < 0.0 ? 0.0 : (r > 0.999 ? 0.999 : (double)r);
+            if (cl != cl) cl = 0.0;      // the square root of a negative sum: the reference's cast of NaN to int is undefined; 0 here
+            v[c] = static_cast<int>(256 * cl);
+        }
+        fprintf(f, "%d %d %d\n", v[0], v[1], v[2]);
+    }
+    return fclose(f) == 0 ? 0 : -2;
 }
 
 }  // extern "C"

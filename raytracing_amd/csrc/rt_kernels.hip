@@ -24,6 +24,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_amd.h"
@@ -2292,6 +2293,118 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     st.seconds_other = tm.seconds[RT_TIME_OTHER];
     if (stats) *stats = st;
     *out_device_sum = this_->d_sum.p;
+    return 0;
+}
+
+// ---------------------------------------------------------------- several GPUs --
+}  // extern "C"
+
+__global__ __launch_bounds__(RT_BLOCK) void k_add_frames(float *__restrict__ sum, const float *__restrict__ other, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) sum[i] += other[i];
+}
+
+struct rt_multi {
+    std::vector<rt_ctx *> ctx;
+    std::vector<rt_scene *> scene;
+    DevBuf staging;            // on device[0]: one frame of another device's sums at a time
+    std::string error;
+};
+static std::string g_multi_error;
+
+extern "C" {
+
+int rt_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int rt_split_samples(int32_t total, int32_t rank, int32_t world, int32_t *begin, int32_t *end) {
+    if (total < 0 || world < 1 || rank < 0 || rank >= world || !begin || !end) return -1;
+    const int32_t base = total / world, rem = total % world;
+    *begin = rank * base + std::min(rank, rem);
+    *end = *begin + base + (rank < rem ? 1 : 0);
+    return 0;
+}
+
+const char *rt_multi_last_error(rt_multi *m) { return m ? m->error.c_str() : g_multi_error.c_str(); }
+
+void rt_multi_destroy(rt_multi *m) {
+    if (!m) return;
+    for (size_t i = 0; i < m->scene.size(); ++i) rt_scene_destroy(m->scene[i]);
+    if (!m->ctx.empty()) { (void)hipSetDevice(m->ctx[0]->device); (void)m->staging.alloc(0); }
+    for (size_t i = 0; i < m->ctx.size(); ++i) rt_shutdown(m->ctx[i]);
+    delete m;
+}
+
+int rt_multi_create(const int32_t *devices, int32_t n_devices, const rt_scene_desc *desc, rt_multi **out) {
+    if (!devices || n_devices < 1 || !desc || !out) { g_multi_error = "rt_multi_create: bad arguments"; return -1; }
+    std::unique_ptr<rt_multi> m(new rt_multi);
+    for (int i = 0; i < n_devices; ++i) {
+        rt_ctx *c = nullptr;
+        if (rt_init(devices[i], &c) != 0) { g_multi_error = std::string("rt_multi_create: ") + rt_last_error(nullptr); rt_multi_destroy(m.release()); return -2; }
+        m->ctx.push_back(c);
+        rt_scene *sc = nullptr;
+        if (rt_scene_create(c, desc, &sc) != 0) { g_multi_error = std::string("rt_multi_create: ") + rt_last_error(c); rt_multi_destroy(m.release()); return -1; }
+        m->scene.push_back(sc);
+    }
+    // the merge copies straight between devices where the hardware allows it (xGMI); where it does not, hipMemcpyPeer stages through the host
+    for (int i = 1; i < n_devices; ++i) {
+        if (devices[i] == devices[0]) continue;
+        int can = 0;
+        (void)hipSetDevice(devices[0]);
+        if (hipDeviceCanAccessPeer(&can, devices[0], devices[i]) == hipSuccess && can) { hipError_t e = hipDeviceEnablePeerAccess(devices[i], 0); if (e != hipSuccess) (void)hipGetLastError(); }
+    }
+    *out = m.release();
+    return 0;
+}
+
+int rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_opts *opts, float *out_sum_rgb, rt_render_stats *stats_per_device,
+                    rt_render_stats *stats_total) {
+    if (!m || !cam || !opts || !out_sum_rgb) return -1;
+    const int n = (int)m->ctx.size();
+    const int32_t total = opts->sample_end - opts->sample_begin;
+    if (total < 0) { m->error = "rt_multi_render: empty or reversed sample range"; return -1; }
+    std::vector<int> rc(n, 0);
+    std::vector<void *> dsum(n, nullptr);
+    std::vector<rt_render_stats> st(n);
+    std::vector<std::thread> pool;
+    for (int i = 0; i < n; ++i)
+        pool.emplace_back([&, i]() {
+            rt_render_opts o = *opts;
+            int32_t b = 0, e = 0;
+            rt_split_samples(total, i, n, &b, &e);
+            o.sample_begin = opts->sample_begin + b; o.sample_end = opts->sample_begin + e;
+            o.flags &= ~RT_RENDER_ACCUMULATE;
+            memset(&st[i], 0, sizeof(st[i]));
+            rc[i] = rt_render_device(m->scene[i], cam, &o, &dsum[i], &st[i]);
+        });
+    for (auto &t : pool) t.join();
+    for (int i = 0; i < n; ++i) if (rc[i] != 0) { m->error = std::string("rt_multi_render: device ") + std::to_string(i) + ": " + rt_last_error(m->ctx[i]); return rc[i]; }
+    // one merge per frame: the other devices' sums are added onto device[0]'s, in device order (the result does not depend on timing)
+    const size_t nfl = (size_t)cam->width * cam->height * 3, bytes = nfl * sizeof(float);
+    rt_ctx *root = m->ctx[0];
+    auto fail = [&](const char *what, hipError_t e) { m->error = std::string("rt_multi_render: ") + what + ": " + hipGetErrorString(e); return -2; };
+    hipError_t e;
+    if ((e = hipSetDevice(root->device)) != hipSuccess) return fail("hipSetDevice", e);
+    if (n > 1 && (e = m->staging.ensure(bytes)) != hipSuccess) return fail("staging buffer", e);
+    for (int i = 1; i < n; ++i) {
+        if ((e = hipMemcpyPeerAsync(m->staging.p, root->device, dsum[i], m->ctx[i]->device, bytes, root->stream)) != hipSuccess) return fail("hipMemcpyPeerAsync", e);
+        hipLaunchKernelGGL(k_add_frames, dim3(std::min<size_t>((nfl + RT_BLOCK - 1) / RT_BLOCK, (size_t)root->n_cu * 8)), dim3(RT_BLOCK), 0, root->stream,
+                           (float *)dsum[0], (const float *)m->staging.p, nfl);
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return fail("k_add_frames", e);
+    if ((e = hipMemcpyAsync(out_sum_rgb, dsum[0], bytes, hipMemcpyDeviceToHost, root->stream)) != hipSuccess) return fail("hipMemcpyAsync", e);
+    if ((e = hipStreamSynchronize(root->stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
+    if (stats_per_device) memcpy(stats_per_device, st.data(), sizeof(rt_render_stats) * n);
+    if (stats_total) {
+        rt_render_stats t; memset(&t, 0, sizeof(t));
+        for (int i = 0; i < n; ++i) {
+            t.samples += st[i].samples; t.rays_closest += st[i].rays_closest; t.rays_shadow += st[i].rays_shadow; t.iterations += st[i].iterations;
+            t.seconds_total = std::max(t.seconds_total, st[i].seconds_total);      // the devices ran side by side
+            t.seconds_trace += st[i].seconds_trace; t.seconds_shade += st[i].seconds_shade; t.seconds_shadow += st[i].seconds_shadow; t.seconds_other += st[i].seconds_other;
+        }
+        *stats_total = t;
+    }
     return 0;
 }
 

@@ -9,13 +9,10 @@ from . import make_opts
 
 
 def split_samples(total, rank, world):
-    """Contiguous, exhaustive, near-equal partition of sample indices [0, total) — rank r gets [begin, end)."""
-    if world < 1 or not (0 <= rank < world):
-        raise ValueError("bad rank/world")
-    base, rem = divmod(total, world)
-    begin = rank * base + min(rank, rem)
-    end = begin + base + (1 if rank < rem else 0)
-    return begin, end
+    """Contiguous, exhaustive, near-equal partition of sample indices [0, total) — rank r gets [begin, end).  The rule lives in
+    the library (rt_split_samples), so that the torchrun path and rt_multi_render share it."""
+    from . import split_samples as _split
+    return _split(total, rank, world)
 
 
 def reduce_frame(frame, dist, dst=0):

@@ -480,18 +480,32 @@ void PathIntegrator::Render(const Scene &scene, int image_width, int image_heigh
     rt_camera cam;
     if (!camera->Describe(&cam)) throw std::runtime_error("PathIntegrator::Render: unsupported camera");
     cam.width = image_width; cam.height = image_height;
-    rt_ctx *ctx = nullptr;
-    if (rt_init(0, &ctx) != 0) throw std::runtime_error(std::string("rt_init: ") + rt_last_error(nullptr));
-    rt_scene *sc = nullptr;
-    if (rt_scene_create(ctx, &fs->desc, &sc) != 0) { std::string e = rt_last_error(ctx); rt_shutdown(ctx); throw std::runtime_error("rt_scene_create: " + e); }
     rt_render_opts o; memset(&o, 0, sizeof(o));
     o.strata_x = sampler->xSamples; o.strata_y = sampler->ySamples; o.sample_begin = 0; o.sample_end = (int)sampler->samplesPerPixel;
     o.max_depth = maxDepth; o.seed_lo = seedLo; o.seed_hi = seedHi;
     lastSum.assign((size_t)image_width * image_height * 3, 0.f);
-    int rc = rt_render(sc, &cam, &o, lastSum.data(), &lastStats);
-    std::string err = rc ? rt_last_error(ctx) : "";
-    rt_scene_destroy(sc); rt_shutdown(ctx);
-    if (rc) throw std::runtime_error("rt_render: " + err);
+    // Every GPU the process sees takes a share of the samples of every pixel (RT_AMD_DEVICES=n caps the number); one GPU renders alone.
+    int nDev = rt_device_count();
+    if (const char *cap = getenv("RT_AMD_DEVICES")) { int c = atoi(cap); if (c >= 1 && c < nDev) nDev = c; }
+    if (nDev > 1) {
+        std::vector<int32_t> devs(nDev);
+        for (int i = 0; i < nDev; ++i) devs[i] = i;
+        rt_multi *m = nullptr;
+        if (rt_multi_create(devs.data(), nDev, &fs->desc, &m) != 0) throw std::runtime_error(rt_multi_last_error(nullptr));
+        int rc = rt_multi_render(m, &cam, &o, lastSum.data(), nullptr, &lastStats);
+        std::string err = rc ? rt_multi_last_error(m) : "";
+        rt_multi_destroy(m);
+        if (rc) throw std::runtime_error(err);
+    } else {
+        rt_ctx *ctx = nullptr;
+        if (rt_init(0, &ctx) != 0) throw std::runtime_error(std::string("rt_init: ") + rt_last_error(nullptr));
+        rt_scene *sc = nullptr;
+        if (rt_scene_create(ctx, &fs->desc, &sc) != 0) { std::string e = rt_last_error(ctx); rt_shutdown(ctx); throw std::runtime_error("rt_scene_create: " + e); }
+        int rc = rt_render(sc, &cam, &o, lastSum.data(), &lastStats);
+        std::string err = rc ? rt_last_error(ctx) : "";
+        rt_scene_destroy(sc); rt_shutdown(ctx);
+        if (rc) throw std::runtime_error("rt_render: " + err);
+    }
     std::vector<uint8_t> px((size_t)image_width * image_height * 3);
     rt_tonemap_u8(lastSum.data(), image_width, image_height, (int)sampler->samplesPerPixel, px.data());
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

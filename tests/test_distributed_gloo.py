@@ -25,6 +25,21 @@ def test_split_samples_is_a_partition():
     assert [split_samples(1024, r, 8) for r in range(8)] == [(128 * r, 128 * r + 128) for r in range(8)]
     with pytest.raises(ValueError):
         split_samples(16, 2, 2)
+    # the rule, spelled out (the library's rt_split_samples is what both the torchrun path and rt_multi_render call)
+    for total, world in ((1000, 8), (5, 8), (0, 3)):
+        base, rem = divmod(total, world)
+        for r in range(world):
+            b = r * base + min(r, rem)
+            assert split_samples(total, r, world) == (b, b + base + (1 if r < rem else 0))
+
+
+def test_multi_device_entry_fails_loudly_without_a_gpu(host_scene):
+    import ctypes as C
+    import raytracing_amd as ra
+    if ra.rt().rt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="HIP"):
+        ra.MultiScene([0, 1], host_scene("cornell").desc_ptr)
 
 
 def _worker(rank, world, port, out_path):

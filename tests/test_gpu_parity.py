@@ -387,3 +387,24 @@ def test_kernel_class_times_add_up(device_scene, host_scene):
     parts = st.seconds_trace + st.seconds_shade + st.seconds_shadow + st.seconds_other
     assert st.seconds_trace > 0 and st.seconds_shade > 0 and st.seconds_other > 0
     assert 0.5 * st.seconds_total < parts <= st.seconds_total * 1.001
+
+
+def test_multi_device_render_merges_sample_shares(host_scene, device_scene):
+    """rt_multi_render: every device renders its share of the samples of every pixel, one merge per frame.  With one GPU in the box the
+    same device is listed two and three times (separate contexts and scene copies): the merged frame must be the single-device frame
+    up to the order of the float additions, run to run identical, and the counters must add up."""
+    hs = host_scene("cornell_metal")
+    cam = hs.camera(160, 120)
+    opts = ra.make_opts(4, 3)
+    want, st = device_scene("cornell_metal").render(cam, opts)
+    for devs in ([0], [0, 0], [0, 0, 0]):
+        ms = ra.MultiScene(devs, hs.desc_ptr)
+        got, per, tot = ms.render(cam, opts)
+        again, _, _ = ms.render(cam, opts)
+        ms.close()
+        assert np.array_equal(got, again)
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
+        assert tot.samples == st.samples and tot.rays_closest == st.rays_closest and tot.rays_shadow == st.rays_shadow
+        assert [p.samples for p in per] == [160 * 120 * (e - b) for b, e in (ra.split_samples(12, r, len(devs)) for r in range(len(devs)))]
+    with pytest.raises(RuntimeError):
+        ra.MultiScene([0, 99], hs.desc_ptr)

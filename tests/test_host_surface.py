@@ -199,3 +199,31 @@ def test_oracle_matches_authors_shipped_render(host_scene, oracle_scene, gold_di
     i8, _ = oracle_scene("cornell").render(cam8, ra.make_opts(1, 1), mode=0)
     u8 = ol.tonemap_u8(i8, 1).reshape(-1, 3).mean(axis=0)
     assert np.all(np.abs(u8 / np.array(stats["cb3_800_1.png"]["mean_u8"]) - 1) < 0.01)
+
+
+def test_ppm_writer_of_the_legacy_entry_file(tmp_path):
+    """P3 text output as RayTracing/main.cpp:28-48,106 writes it: header, one 'r g b' line per pixel, sqrt(scale * c) computed in double
+    with scale = 1.0 / spp and stored as float, NaN -> 0, 256 * clamp(c, 0, 0.999) truncated.  The header layout is the one of the PPM
+    files the reference ships (checked against one when the reference tree is mounted)."""
+    rng = np.random.default_rng(9)
+    w, h, spp = 7, 5, 37
+    img = (rng.random((h, w, 3)) ** 3 * 90).astype(np.float32)
+    img[0, 0] = [np.nan, 0, 1e9]; img[1, 1] = [-1.0, 36.9999, 37.0]
+    path = tmp_path / "out.ppm"
+    ra.write_ppm(path, img, spp)
+    text = path.read_text()
+    lines = text.split("\n")
+    assert lines[0] == "P3" and lines[1] == "%d %d" % (w, h) and lines[2] == "255" and lines[-1] == "" and len(lines) == 3 + w * h + 1
+    got = np.array([[int(v) for v in ln.split()] for ln in lines[3:-1]]).reshape(h, w, 3)
+    r = np.where(np.isnan(img), np.float32(0), img)
+    with np.errstate(invalid="ignore"):
+        c = np.sqrt(np.float64(1.0 / spp) * r.astype(np.float64)).astype(np.float32).astype(np.float64)
+    c = np.where(np.isnan(c), 0.999 + 1, c)     # sqrt of a negative sum: NaN compares false with both clamp bounds ...
+    want = (256 * np.clip(c, 0.0, 0.999)).astype(int)
+    neg = r < 0
+    assert np.array_equal(got[~neg], want[~neg])
+    assert got[0, 0].tolist() == [0, 0, 255] and got[1, 1, 2] == 255 and got[1, 1, 1] == int(256 * np.float32(np.sqrt(np.float64(1.0 / 37) * np.float64(np.float32(36.9999)))))
+    shipped = "/root/reference/RayTracing/result10.ppm"
+    if os.path.exists(shipped):
+        head = open(shipped).read(200).split("\n")
+        assert head[0] == "P3" and len(head[1].split()) == 2 and head[2] == "255" and len(head[3].split()) == 3
