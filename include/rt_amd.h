@@ -81,7 +81,31 @@ typedef struct rt_material {
     int32_t pad;
 } rt_material;
 
-/* DiffuseAreaLight on one triangle (include/core/light.cpp:28-54, light.h:68-89). */
+enum { RT_LIGHT_AREA = 0, RT_LIGHT_INFINITE = 1 };
+
+/* InfiniteAreaLight (include/core/infinite.h:14-40, infinite.cpp:4-106): everything Sample_Li reads, as the constructor leaves it.
+ * texels: level 0 of Lmap (after the resample to powers of two, mipmap.h:70-121), row-major RGB floats.  The Distribution2D
+ * (include/core/sampling.h:15-91, sampling.cpp:113-123) over the nu x nv = 2 width x 2 height image of luminance x sin(theta):
+ * row v of func / cdf is pConditionalV[v] (nu values / nu + 1 values), func_int[v] its funcInt (= the marginal's func),
+ * marginal_cdf / marginal_int the marginal's cdf (nv + 1 values) and funcInt.  world_radius: Scene::WorldBound().BoundingSphere
+ * (infinite.h:20-22, scene.cpp:6-13). */
+typedef struct rt_env_light {
+    float        light_to_world[16], world_to_light[16];
+    int32_t      width, height;
+    const float *texels;
+    int32_t      nu, nv;
+    const float *func;
+    const float *cdf;
+    const float *func_int;
+    const float *marginal_cdf;
+    float        marginal_int;
+    float        world_center[3];
+    float        world_radius;
+} rt_env_light;
+
+/* One entry of Scene::lights (include/core/scene.h:18), in the scene script's order: the index is what
+ * UniformSampleOneLight picks (integrator.cpp:63).  RT_LIGHT_AREA: a DiffuseAreaLight on one triangle
+ * (include/core/light.cpp:28-54, light.h:68-89).  RT_LIGHT_INFINITE: env names an rt_env_light, prim is -1. */
 typedef struct rt_light {
     int32_t prim;        /* index into the ORIGINAL primitive list */
     float   Le[3];
@@ -90,6 +114,8 @@ typedef struct rt_light {
                             divides by Triangle::Area() computed from the vertices (triangle.cpp:222-227,246), as the reference does */
     int32_t flip_normal; /* the shape's reverseOrientation ^ transformSwapsHandedness: Triangle::Sample turns the sampled
                             normal round when the mesh has no vertex normals (triangle.cpp:237-243); Intersect never does */
+    int32_t kind;        /* RT_LIGHT_* */
+    int32_t env;         /* RT_LIGHT_INFINITE: index into rt_scene_desc.env_lights */
 } rt_light;
 
 /* The whole scene, flattened.  Primitive arrays are in the ORIGINAL order the
@@ -123,6 +149,9 @@ typedef struct rt_scene_desc {
     int32_t            n_nodes;
     const rt_bvh_node *bvh_nodes;      /* optional */
     const int32_t     *prim_order;     /* n_prims, required iff bvh_nodes != NULL */
+
+    int32_t             n_env_lights;
+    const rt_env_light *env_lights;
 } rt_scene_desc;
 
 /* PerspectiveCamera state that GenerateRay reads (include/core/camera.cpp:52-58,

@@ -33,6 +33,9 @@
 // re-declared here with the layout of bvh.cpp:43-47 (checked against sizeof below).
 #define private public
 #include "core/bvh.h"
+#include "core/sampling.h"
+#include "core/mipmap.h"
+#include "core/infinite.h"
 #undef private
 #include "core/camera.h"
 #include "core/imagemap.h"
@@ -115,9 +118,20 @@ static void LoadScene(const std::string &path, RefScene &rs) {
         default: fprintf(stderr, "bad material\n"); exit(2);
         }
     }
-    struct LightRec { int32_t prim; float Le[3]; int32_t two; float area; int32_t flip; };
+    struct LightRec { int32_t prim; float Le[3]; int32_t two; float area; int32_t flip; int32_t kind; int32_t env; };
     auto lrec = r.arr<LightRec>(n_lights);
     rs.lights.resize(n_lights);
+    // infinite area lights: transform, scale and the .hdr file; everything else is the reference constructor's doing (infinite.cpp:4-71)
+    int n_env = r.get<int32_t>();
+    struct EnvRec { float m[16], mi[16], L[3]; std::string path; };
+    std::vector<EnvRec> envs(n_env);
+    for (EnvRec &e : envs) { for (float &v : e.m) v = r.get<float>(); for (float &v : e.mi) v = r.get<float>(); for (float &v : e.L) v = r.get<float>(); e.path = r.str(); }
+    for (int i = 0; i < n_lights; ++i)
+        if (lrec[i].kind == RT_LIGHT_INFINITE) {
+            const EnvRec &e = envs[lrec[i].env];
+            Float m[4][4], mi[4][4]; memcpy(m, e.m, 64); memcpy(mi, e.mi, 64);
+            rs.lights[i] = std::make_shared<InfiniteAreaLight>(Transform(Matrix4x4(m), Matrix4x4(mi)), Spectrum(e.L[0], e.L[1], e.L[2]), 1, e.path);
+        }
     Transform *I = Keep(rs, Transform());
     for (int i = 0; i < n_prims; ++i) {
         std::shared_ptr<Shape> shape;
@@ -183,6 +197,37 @@ int main(int argc, char **argv) {
         std::string out; out.resize(4 + 32 * (size_t)total + 4 * (size_t)n);
         memcpy(&out[0], &total, 4); memcpy(&out[4], nodes, 32 * (size_t)total); memcpy(&out[4 + 32 * (size_t)total], order.data(), 4 * (size_t)n);
         WriteAll(argv[3], out.data(), out.size());
+        return 0;
+    }
+    if (cmd == "env") {          // env scene.bin out.bin : tables of the scene's first InfiniteAreaLight as its constructor and Preprocess leave them
+        RefScene rs; LoadScene(argv[2], rs);
+        const InfiniteAreaLight *env = nullptr;
+        for (auto &l : rs.lights) if (!env) env = dynamic_cast<const InfiniteAreaLight *>(l.get());
+        if (!env) { fprintf(stderr, "no infinite light\n"); return 2; }
+        int w = env->Lmap->Width(), h = env->Lmap->Height();
+        const Distribution2D &d2 = *env->distribution;
+        int nv = d2.pMarginal->Count(), nu = d2.pConditionalV[0]->Count();
+        std::vector<float> out;
+        auto put = [&](float v) { out.push_back(v); };
+        put((float)w); put((float)h); put((float)nu); put((float)nv);
+        for (int t = 0; t < h; ++t) for (int s2 = 0; s2 < w; ++s2) { const RGBSpectrum &c = env->Lmap->Texel(0, s2, t); put(c[0]); put(c[1]); put(c[2]); }
+        for (int v = 0; v < nv; ++v) for (float f : d2.pConditionalV[v]->func) put(f);
+        for (int v = 0; v < nv; ++v) for (float f : d2.pConditionalV[v]->cdf) put(f);
+        for (int v = 0; v < nv; ++v) put(d2.pConditionalV[v]->funcInt);
+        for (float f : d2.pMarginal->cdf) put(f);
+        put(d2.pMarginal->funcInt);
+        put(env->worldCenter.x); put(env->worldCenter.y); put(env->worldCenter.z); put(env->worldRadius);
+        // a few Sample_Li known answers: (ref point, u) -> wi, pdf, Li
+        RNG rng(17);
+        for (int i = 0; i < 256; ++i) {
+            Point2f u(rng.UniformFloat(), rng.UniformFloat());
+            Interaction ref(Point3f(rng.UniformFloat() * 4, rng.UniformFloat() * 4, rng.UniformFloat() * 4), 0.f);
+            Vector3f wi; Float pdf = 0; VisibilityTester vis;
+            Spectrum Li = env->Sample_Li(ref, u, &wi, &pdf, &vis);
+            put(u[0]); put(u[1]); put(ref.p.x); put(ref.p.y); put(ref.p.z); put(wi.x); put(wi.y); put(wi.z); put(pdf); put(Li[0]); put(Li[1]); put(Li[2]);
+            put(vis.P1().p.x); put(vis.P1().p.y); put(vis.P1().p.z);
+        }
+        WriteAll(argv[3], out.data(), out.size() * 4);
         return 0;
     }
     if (cmd == "trace") {        // trace scene.bin rays.bin(n x 7 f32) out.bin : per ray [prim i32][t f32][u f32][v f32][any u32]

@@ -12,7 +12,7 @@
 //   camera               camera.cpp:52-58
 //   sampler              rng.h:85-100, sampling.cpp:5-23, sampler.cpp:7-82, stratified.cpp:4-35
 //   path estimator       integrator.cpp:53-102,236-281,289-308
-//   lights               light.cpp:43-54, shape.cpp:20-31, interaction.h:18-32
+//   lights               light.cpp:43-54, shape.cpp:20-31, interaction.h:18-32, infinite.cpp:83-106, sampling.h:15-91
 //   materials / BSDFs    material.cpp:5-82, reflection.cpp:6-300, reflection.h:11-180
 //   microfacets          microfacet.cpp:84-107,149-236, microfacet.h:14-78
 //   textures             texture.cpp:8-13, mipmap.h:152-200
@@ -139,6 +139,7 @@ struct Scene {
     std::vector<std::vector<float>> texel_store; std::vector<rt_light> lights;
     std::vector<rt_bvh_node> nodes; std::vector<int32_t> order;
     int n_prims = 0;
+    std::vector<rt_env_light> envs; std::vector<std::vector<float>> env_store;    // infinite lights and the tables they point at
 };
 
 struct Bounds { V3 pMin, pMax; };
@@ -1019,6 +1020,49 @@ inline RGB LightL(const rt_light &l, V3 n, V3 w) {
     return (l.two_sided || Dot(n, w) > 0) ? rgb(l.Le[0], l.Le[1], l.Le[2]) : rgb1(0.f);
 }
 
+// pbrt.h:213-226
+template <typename Pred> inline int FindInterval(int size, const Pred &pred) {
+    int first = 0, len = size;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (pred(middle)) { first = middle + 1; len -= half + 1; }
+        else len = half;
+    }
+    return Clamp(first - 1, 0, size - 2);
+}
+// Distribution1D::SampleContinuous (sampling.h:30-40) over func[0..n), cdf[0..n], funcInt
+inline Float SampleContinuous1D(const float *func, const float *cdf, int n, Float funcInt, Float u, Float *pdf, int *off) {
+    int offset = FindInterval(n + 1, [&](int index) { return cdf[index] <= u; });
+    if (off) *off = offset;
+    Float du = u - cdf[offset];
+    if ((cdf[offset + 1] - cdf[offset]) > 0) du /= (cdf[offset + 1] - cdf[offset]);
+    if (pdf) *pdf = (funcInt > 0) ? func[offset] / funcInt : 0;
+    return (offset + du) / n;
+}
+// InfiniteAreaLight::Sample_Li (infinite.cpp:83-106) with Distribution2D::SampleContinuous (sampling.h:72-79) and
+// MIPMap::Lookup(st) = triangle(0, st) for a zero filter width (mipmap.h:173-200).  Returns Li; *p1 = the far end of the
+// visibility segment.
+RGB EnvSampleLi(const rt_env_light &e, V3 refP, Float u0, Float u1, V3 *wi, Float *pdf, V3 *p1) {
+    Float pdfs[2]; int v;
+    Float d1 = SampleContinuous1D(e.func_int, e.marginal_cdf, e.nv, e.marginal_int, u1, &pdfs[1], &v);
+    Float d0 = SampleContinuous1D(e.func + (size_t)v * e.nu, e.cdf + (size_t)v * (e.nu + 1), e.nu, e.func_int[v], u0, &pdfs[0], nullptr);
+    Float mapPdf = pdfs[0] * pdfs[1];
+    if (mapPdf == 0) return rgb1(0.f);
+    Float theta = d1 * Pi, phi = d0 * 2 * Pi;
+    Float cosTheta = std::cos(theta), sinTheta = std::sin(theta);
+    Float sinPhi = std::sin(phi), cosPhi = std::cos(phi);
+    *wi = XfVector(e.light_to_world, mk(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta));
+    *pdf = mapPdf / (2 * Pi * Pi * sinTheta);
+    if (sinTheta == 0) *pdf = 0;
+    *p1 = refP + *wi * (2 * e.world_radius);
+    // triangle(0, uv), Repeat wrap
+    Float s = d0 * e.width - 0.5f, t = d1 * e.height - 0.5f;
+    int s0 = (int)std::floor(s), t0 = (int)std::floor(t);
+    Float ds = s - s0, dt = t - t0;
+    auto texel = [&](int a, int b) { const float *px = e.texels + 3 * ((size_t)ModI(b, e.height) * e.width + ModI(a, e.width)); return rgb(px[0], px[1], px[2]); };
+    return (1 - ds) * (1 - dt) * texel(s0, t0) + (1 - ds) * dt * texel(s0, t0 + 1) + ds * (1 - dt) * texel(s0 + 1, t0) + ds * dt * texel(s0 + 1, t0 + 1);
+}
+
 // integrator.cpp:53-102 + light.cpp:43-54 + shape.cpp:20-31 + triangle.cpp:229-248 + interaction.h:27-32
 RGB UniformSampleOneLight(const Scene &sc, const SurfaceInteraction &si, const BSDF &bsdf, Sampler &smp, PathCounters *pc) {
     int nLights = (int)sc.lights.size();
@@ -1028,6 +1072,24 @@ RGB UniformSampleOneLight(const Scene &sc, const SurfaceInteraction &si, const B
     int lightNum = std::min((int)(pick * nLights), nLights - 1);
     Float lightPdfSel = Float(1) / nLights;
     const rt_light &light = sc.lights[lightNum];
+    if (light.kind == RT_LIGHT_INFINITE) {      // EstimateDirect (integrator.cpp:74-102) around InfiniteAreaLight::Sample_Li
+        V3 wi = mk(0, 0, 0), p1 = mk(0, 0, 0); Float lightPdf = 0;
+        RGB Li = EnvSampleLi(sc.envs[light.env], si.p, u0, u1, &wi, &lightPdf, &p1);
+        RGB Ld = rgb1(0.f);
+        if (lightPdf > 0 && !IsBlack(Li)) {
+            RGB f = bsdf.f(si.wo, wi, BSDF_ALL & ~BSDF_SPECULAR) * AbsDot(wi, si.n);
+            if (!IsBlack(f)) {
+                // VisibilityTester(ref, Interaction(p1)) -> SpawnRayTo (interaction.h:27-32); the far end has no normal, so no offset
+                V3 origin = OffsetRayOrigin(si.p, si.n, p1 - si.p);
+                V3 target = OffsetRayOrigin(p1, mk(0, 0, 0), origin - p1);
+                Ray sr = {origin, target - origin, 1 - ShadowEpsilon};
+                if (pc) pc->shadow++;
+                if (IntersectAny(sc, sr, nullptr)) Li = rgb1(0.f);
+                if (!IsBlack(Li)) Ld = Ld + f * Li / lightPdf;
+            }
+        }
+        return Ld / lightPdfSel;
+    }
     // Triangle::Sample
     size_t g = (size_t)sc.prim_geom[light.prim];
     const float *P = &sc.tri_p[9 * g];
@@ -1157,6 +1219,13 @@ orc_scene *orc_scene_create(const rt_scene_desc *d) {
             s.textures[i].texels = s.texel_store[i].data();
         }
     if (d->n_lights) s.lights.assign(d->lights, d->lights + d->n_lights);
+    for (int i = 0; i < d->n_env_lights; ++i) {
+        rt_env_light e = d->env_lights[i];
+        auto keep = [&](const float *p, size_t n) { s.env_store.emplace_back(p, p + n); return (const float *)s.env_store.back().data(); };
+        e.texels = keep(e.texels, 3 * (size_t)e.width * e.height); e.func = keep(e.func, (size_t)e.nu * e.nv);
+        e.cdf = keep(e.cdf, (size_t)e.nv * (e.nu + 1)); e.func_int = keep(e.func_int, e.nv); e.marginal_cdf = keep(e.marginal_cdf, e.nv + 1);
+        s.envs.push_back(e);
+    }
     if (d->bvh_nodes) {
         s.nodes.assign(d->bvh_nodes, d->bvh_nodes + d->n_nodes);
         s.order.assign(d->prim_order, d->prim_order + d->n_prims);
@@ -1299,6 +1368,14 @@ int orc_film_sample(uint32_t pixel, uint32_t sample, uint32_t k0, uint32_t k1, i
 }
 int orc_texture_eval(orc_scene *h, int tex, float u, float v, float *out) {
     RGB c = EvalTexture(h->s, tex, u, v); out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; return 0;
+}
+// InfiniteAreaLight::Sample_Li of env light `env` for reference point p and sample u: out = wi[3], pdf, Li[3], p1[3] (10 floats)
+int orc_env_sample(orc_scene *h, int env, const float *p, float u0, float u1, float *out10) {
+    if (env < 0 || env >= (int)h->s.envs.size()) return -1;
+    V3 wi = mk(0, 0, 0), p1 = mk(0, 0, 0); Float pdf = 0;
+    RGB Li = EnvSampleLi(h->s.envs[env], mk(p[0], p[1], p[2]), u0, u1, &wi, &pdf, &p1);
+    float v[10] = {wi.x, wi.y, wi.z, pdf, Li[0], Li[1], Li[2], p1.x, p1.y, p1.z};
+    memcpy(out10, v, sizeof(v)); return 0;
 }
 // Interaction at the closest hit of one ray: p, n, wo, uv, dpdu (14 floats) ; returns prim or -1.
 int orc_interaction(orc_scene *h, const float *o, const float *d, float tmax, float *out14) {

@@ -55,6 +55,21 @@ def decode_image(data):
     return out
 
 
+def write_hdr(path, rgb):
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    if host().rth_write_hdr(str(path).encode(), rgb.shape[1], rgb.shape[0], capi.fptr(rgb)) != 0:
+        raise RuntimeError("cannot write " + str(path))
+
+
+def read_hdr(path, flip=False):
+    w = C.c_int(0); h = C.c_int(0)
+    if host().rth_read_hdr(str(path).encode(), int(flip), C.byref(w), C.byref(h), None) != 0:
+        raise RuntimeError("cannot read " + str(path))
+    out = np.zeros((h.value, w.value, 3), np.float32)
+    host().rth_read_hdr(str(path).encode(), int(flip), C.byref(w), C.byref(h), capi.fptr(out))
+    return out
+
+
 def model_probe(path, apply_node_transforms=False):
     """Triangles (n, 3, 3), uvs (n, 3, 2) and the (base colour, metal-roughness) texture names ModelLoad takes from a .gltf / .glb."""
     n = C.c_int(0)
@@ -88,6 +103,12 @@ class HostScene:
     def texture_source(self, index):
         """File the image texture `index` was decoded from ("" when there is none)."""
         return host().rth_scene_texture_source(self._h, index).decode()
+
+    def env_source(self, index):
+        """(.hdr path, scale) the infinite light `index` was constructed with."""
+        L = (C.c_float * 3)()
+        path = host().rth_scene_env_source(self._h, index, L).decode()
+        return path, list(L)
 
     def nodes(self):
         d = self.desc

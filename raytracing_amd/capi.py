@@ -36,7 +36,15 @@ class Material(C.Structure):
 
 
 class Light(C.Structure):
-    _fields_ = [("prim", C.c_int32), ("Le", C.c_float * 3), ("two_sided", C.c_int32), ("area", C.c_float), ("flip_normal", C.c_int32)]
+    _fields_ = [("prim", C.c_int32), ("Le", C.c_float * 3), ("two_sided", C.c_int32), ("area", C.c_float), ("flip_normal", C.c_int32),
+                ("kind", C.c_int32), ("env", C.c_int32)]
+
+
+class EnvLight(C.Structure):
+    _fields_ = [("light_to_world", C.c_float * 16), ("world_to_light", C.c_float * 16), ("width", C.c_int32), ("height", C.c_int32),
+                ("texels", C.POINTER(C.c_float)), ("nu", C.c_int32), ("nv", C.c_int32), ("func", C.POINTER(C.c_float)),
+                ("cdf", C.POINTER(C.c_float)), ("func_int", C.POINTER(C.c_float)), ("marginal_cdf", C.POINTER(C.c_float)),
+                ("marginal_int", C.c_float), ("world_center", C.c_float * 3), ("world_radius", C.c_float)]
 
 
 class SceneDesc(C.Structure):
@@ -50,6 +58,7 @@ class SceneDesc(C.Structure):
         ("n_textures", C.c_int32), ("textures", C.POINTER(Texture)),
         ("n_lights", C.c_int32), ("lights", C.POINTER(Light)),
         ("n_nodes", C.c_int32), ("bvh_nodes", C.POINTER(BvhNode)), ("prim_order", C.POINTER(C.c_int32)),
+        ("n_env_lights", C.c_int32), ("env_lights", C.POINTER(EnvLight)),
     ]
 
 
@@ -132,9 +141,12 @@ def load_rt_host():
     lib.rth_scene_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int64]; lib.rth_scene_build.restype = vp
     lib.rth_scene_desc.argtypes = [vp]; lib.rth_scene_desc.restype = C.POINTER(SceneDesc)
     lib.rth_scene_texture_source.argtypes = [vp, C.c_int]; lib.rth_scene_texture_source.restype = C.c_char_p
+    lib.rth_scene_env_source.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]; lib.rth_scene_env_source.restype = C.c_char_p
     lib.rth_scene_camera.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Camera)]
     lib.rth_scene_free.argtypes = [vp]; lib.rth_scene_free.restype = None
     lib.rth_register_image.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint8)]; lib.rth_register_image.restype = None
+    lib.rth_write_hdr.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    lib.rth_read_hdr.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]
     lib.rth_decode_image.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint8)]
     lib.rth_model_probe.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_char_p, C.c_int]
     lib.rth_render_like_main.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,

@@ -35,6 +35,14 @@ struct DevLight {
     float Le[3];
     float area;          // 0.5 * |Cross(p1-p0, p2-p0)|, triangle.cpp:222-227
     int two_sided, has_n;
+    int kind, env;       // RT_LIGHT_INFINITE: index into DevScene::envs (the triangle fields are unused)
+};
+// InfiniteAreaLight as Sample_Li reads it (infinite.cpp:83-106): radiance map level 0, Distribution2D tables, transform, scene radius.
+struct DevEnv {
+    float l2w[12];                 // rows 0..2 of LightToWorld
+    int width, height, nu, nv;
+    const float *texels, *func, *cdf, *func_int, *marginal_cdf;
+    float marginal_int, world_radius;
 };
 
 // Scene as the kernels see it.  Everything geometric is indexed by BVH leaf slot.
@@ -57,6 +65,7 @@ struct DevScene {
     int n_quads, quad_stack_cap;
     uint32_t pad;
     int n_materials, n_textures;
+    const DevEnv *envs;       // infinite area lights
 };
 
 struct F3 { float x, y, z; };
@@ -346,6 +355,48 @@ __device__ __forceinline__ F3 eval_texture(const DevTexture &t, float u, float v
               A[2] * w00 + B[2] * w01 + Cc[2] * w10 + D[2] * w11);
 }
 __device__ __forceinline__ F3 clamp0(F3 a) { return f3(a.x < 0.f ? 0.f : a.x, a.y < 0.f ? 0.f : a.y, a.z < 0.f ? 0.f : a.z); }   // Spectrum::Clamp(0, inf)
+
+// Distribution1D::SampleContinuous (sampling.h:30-40) with FindInterval (pbrt.h:213-226) over func[0..n), cdf[0..n].
+__device__ __forceinline__ float sample_continuous_1d(const float *func, const float *cdf, int n, float funcInt, float u, float &pdf, int &offset) {
+    int first = 0, len = n + 1;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
+        else len = half;
+    }
+    offset = min(max(first - 1, 0), n - 1);
+    float c0 = cdf[offset], c1 = cdf[offset + 1];
+    float du = u - c0;
+    if ((c1 - c0) > 0) du /= (c1 - c0);
+    pdf = (funcInt > 0) ? func[offset] / funcInt : 0.f;
+    return (offset + du) / n;
+}
+// InfiniteAreaLight::Sample_Li (infinite.cpp:83-106): Distribution2D::SampleContinuous (sampling.h:72-79), direction from the
+// (u, v) of the map, pdf with respect to solid angle, radiance = bilinear level-0 lookup (MIPMap::Lookup with zero width).
+__device__ __forceinline__ F3 env_sample_li(const DevEnv &e, float u0, float u1, F3 &wi, float &pdf) {
+    float pdf0, pdf1; int v, dummy;
+    float d1 = sample_continuous_1d(e.func_int, e.marginal_cdf, e.nv, e.marginal_int, u1, pdf1, v);
+    float d0 = sample_continuous_1d(e.func + (size_t)v * e.nu, e.cdf + (size_t)v * (e.nu + 1), e.nu, e.func_int[v], u0, pdf0, dummy);
+    float mapPdf = pdf0 * pdf1;
+    pdf = 0.f; wi = f3(0.f, 0.f, 1.f);
+    if (mapPdf == 0) return f3(0.f, 0.f, 0.f);
+    float theta = d1 * RT_PI, phi = d0 * 2 * RT_PI;
+    float sinTheta, cosTheta, sinPhi, cosPhi;
+    sincosf(theta, &sinTheta, &cosTheta); sincosf(phi, &sinPhi, &cosPhi);
+    wi = xf_vector(e.l2w, f3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta));
+    pdf = mapPdf / (2 * RT_PI * RT_PI * sinTheta);
+    if (sinTheta == 0) pdf = 0.f;
+    float s = d0 * e.width - 0.5f, t = d1 * e.height - 0.5f;
+    float fs = floorf(s), ft = floorf(t);
+    int s0 = (int)fs, t0 = (int)ft;
+    float ds = s - s0, dt = t - t0;
+    int sa = mod_wrap(s0, e.width), sb = mod_wrap(s0 + 1, e.width), ta = mod_wrap(t0, e.height), tb = mod_wrap(t0 + 1, e.height);
+    const float *A = e.texels + 3 * ((size_t)ta * e.width + sa), *B = e.texels + 3 * ((size_t)tb * e.width + sa);
+    const float *Cc = e.texels + 3 * ((size_t)ta * e.width + sb), *D = e.texels + 3 * ((size_t)tb * e.width + sb);
+    float w00 = (1 - ds) * (1 - dt), w01 = (1 - ds) * dt, w10 = ds * (1 - dt), w11 = ds * dt;
+    return f3(A[0] * w00 + B[0] * w01 + Cc[0] * w10 + D[0] * w11, A[1] * w00 + B[1] * w01 + Cc[1] * w10 + D[1] * w11,
+              A[2] * w00 + B[2] * w01 + Cc[2] * w10 + D[2] * w11);
+}
 
 // reflection.h:11-69
 __device__ __forceinline__ float cos2theta(F3 w) { return w.z * w.z; }

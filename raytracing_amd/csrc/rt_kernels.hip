@@ -756,7 +756,8 @@ struct ShadeOut { bool has_shadow, has_next; uint32_t nstate; F3 so, sd, sc3, no
 
 // Shading of one path at its hit (integrator.cpp:258-280): BSDF of material class MAT, next-event estimation, BSDF sampling,
 // Russian roulette.  `sc` may point its tables at LDS copies.
-template <int MAT>
+// ENV: the scene may hold infinite area lights (a compile-time switch, so that the kernels of scenes without one do not carry the code).
+template <int MAT, bool ENV = false>
 __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParams &rp, F3 o, F3 d, F3 T, uint32_t id, uint32_t state, int slot, float hit_t,
                                            float hit_b0, float hit_b1, float hit_b2, ShadeOut &out) {
     out.has_shadow = false; out.has_next = false; out.nstate = 0;
@@ -837,6 +838,33 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
             float selPdf = 1.f / nL;
             const DevLight &L = sc.lights[ln];
             float u0 = u32_to_unit(a1), u1 = u32_to_unit(a2);
+            if (ENV && L.kind == RT_LIGHT_INFINITE) {
+                // EstimateDirect (integrator.cpp:74-102) around InfiniteAreaLight::Sample_Li (infinite.cpp:83-106); the visibility
+                // segment ends at p + wi * 2 * worldRadius, a point without a normal, so that end gets no offset (interaction.h:27-36)
+                const DevEnv &E = sc.envs[L.env];
+                F3 wi; float pdf;
+                F3 Li = env_sample_li(E, u0, u1, wi, pdf);
+                if (pdf > 0 && !black3(Li)) {
+                    F3 wol = to_local(sp, sp.wo), wil = to_local(sp, wi);
+                    F3 f = f3(0.f, 0.f, 0.f);
+                    if (wol.z != 0) {
+                        bool reflect = dot3(wi, sp.n) * dot3(sp.wo, sp.n) > 0;
+                        if (reflect) {
+                            f = lobe_f(lobe, wol, wil);
+                            if (nlobes == 2) f = f + lobe_f(lobe2, wol, wil);
+                        }
+                    }
+                    float ad = fabsf(dot3(wi, sp.n));
+                    f = f3(f.x * ad, f.y * ad, f.z * ad);
+                    if (!black3(f)) {
+                        F3 far_end = sp.p + (2 * E.world_radius) * wi;
+                        F3 origin = offset_ray_origin(sp.p, sp.n, far_end - sp.p);
+                        F3 target = offset_ray_origin(far_end, f3(0.f, 0.f, 0.f), origin - far_end);
+                        F3 Ld = cdiv(cdiv(f * Li, pdf), selPdf);
+                        out.has_shadow = true; out.so = origin; out.sd = target - origin; out.sc3 = T * Ld;
+                    }
+                }
+            } else {
             F3 p0 = f3(L.p0[0], L.p0[1], L.p0[2]), p1 = f3(L.p1[0], L.p1[1], L.p1[2]), p2 = f3(L.p2[0], L.p2[1], L.p2[2]);
             float su0 = sqrtf(u0);
             float lb0 = 1 - su0, lb1 = u1 * su0;                       // UniformSampleTriangle, sampling.cpp:108-111
@@ -881,6 +909,7 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
                     out.has_shadow = true; out.so = origin; out.sd = target - origin; out.sc3 = T * Ld;
                 }
             }
+            }
         }
         if (lobe.kind != 0) sample_bsdf(lobe, lobe2, nlobes);
     }
@@ -892,7 +921,7 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
 // LDS copy of the pair records, instead of going through the shadow queue to k_shadow; the unoccluded light is added to
 // the path's radiance slot at once.  The tables live in dynamic LDS sized to the scene (shade_lds_bytes).
 // (matte and mirror are held at five waves per SIMD, which is also what their LDS allows; the heavier materials take the registers they need)
-template <int MAT, int TABLES, bool FUSE>
+template <int MAT, int TABLES, bool FUSE, bool ENV = false>
 __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIRROR || MAT == RT_MAT_METALROUGH) ? 5 : 4) void k_shade(DevScene sc_in, RenderParams rp, int bounce, PathQueue q, PathQueue qn, HitBuf hb, const uint32_t *cls_list,
                                                      uint32_t cap, uint32_t segcap, ShadowQueue sq, BounceCounts *counts, float4 *lbuf, BounceStats *stats) {
     constexpr bool LDS_TABLES = TABLES == 1;
@@ -954,7 +983,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
             id = q.id[i];
             uint32_t state = q.state[i];
             ShadeOut out;
-            shade_path<MAT>(sc, rp, o, d, T, id, state, hb.slot[i], hb.t[i], hb.b0[i], hb.b1[i], hb.b2[i], out);
+            shade_path<MAT, ENV>(sc, rp, o, d, T, id, state, hb.slot[i], hb.t[i], hb.b0[i], hb.b1[i], hb.b2[i], out);
             has_shadow = out.has_shadow; has_next = out.has_next; nstate = out.nstate;
             so = out.so; sd = out.sd; sc3 = out.sc3; no = out.no; nd = out.nd; nT = out.nT;
         }
@@ -1534,7 +1563,7 @@ struct rt_scene {
     std::vector<rt_bvh_node> nodes; std::vector<int32_t> order;
     int n_prims = 0;
     bool classes[RT_NUM_CLASSES] = {false, false, false, false, false, false};
-    DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_spill, d_pairs, d_quads;
+    DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_envs, d_spill, d_pairs, d_quads;
     int interior_depth = 0;
     std::vector<float> survival;     // fraction of a pass's paths still alive at each bounce, from the last pass that ran every bounce (k_finish)
     std::vector<DevBuf *> d_texels;
@@ -1624,10 +1653,22 @@ static std::string check_desc(const rt_scene_desc *d) {
         for (int k = 0; k < 4; ++k)
             if (m.tex[k] >= d->n_textures || m.tex[k] < -1 || (k < need && m.tex[k] < 0)) return "material texture slot out of range";
     }
+    if (d->n_env_lights < 0 || (d->n_env_lights > 0 && !d->env_lights)) return "env_lights is NULL";
     for (int i = 0; i < d->n_lights; ++i) {
         const rt_light &L = d->lights[i];
+        if (L.kind == RT_LIGHT_INFINITE) {
+            if (L.env < 0 || L.env >= d->n_env_lights) return "infinite light references out of range";
+            continue;
+        }
+        if (L.kind != RT_LIGHT_AREA) return "unknown light kind";
         if (L.prim < 0 || L.prim >= d->n_prims || d->prim_kind[L.prim] != RT_PRIM_TRIANGLE) return "area lights must be triangles";
         if (d->prim_light[L.prim] != i) return "a light's primitive does not point back at the light";
+    }
+    for (int i = 0; i < d->n_env_lights; ++i) {
+        const rt_env_light &E = d->env_lights[i];
+        if (E.width <= 0 || E.height <= 0 || E.nu <= 0 || E.nv <= 0 || (size_t)E.width * E.height > ((size_t)1 << 28) || (size_t)E.nu * E.nv > ((size_t)1 << 28))
+            return "infinite light with an empty or oversized map";
+        if (!E.texels || !E.func || !E.cdf || !E.func_int || !E.marginal_cdf) return "infinite light with a NULL table";
     }
     return "";
 }
@@ -1761,6 +1802,8 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     std::vector<DevLight> lights((size_t)std::max(1, d->n_lights));
     for (int i = 0; i < d->n_lights; ++i) {
         const rt_light &L = d->lights[i]; DevLight &D = lights[i]; memset(&D, 0, sizeof(D));
+        D.kind = L.kind; D.env = L.env;
+        if (L.kind == RT_LIGHT_INFINITE) continue;
         if (L.prim < 0 || L.prim >= d->n_prims || d->prim_kind[L.prim] != RT_PRIM_TRIANGLE) { set_error(ctx, "rt_scene_create: area lights must be triangles"); return -1; }
         size_t g = (size_t)d->prim_geom[L.prim];
         const float *P = d->tri_p + 9 * g;
@@ -1788,6 +1831,22 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
             D.texels = (const float *)b->p;
         } else if (T.kind != RT_TEX_CONST) { set_error(ctx, "rt_scene_create: unknown texture kind"); return -1; }
     }
+    std::vector<DevEnv> envs((size_t)d->n_env_lights);
+    for (int i = 0; i < d->n_env_lights; ++i) {
+        const rt_env_light &E = d->env_lights[i]; DevEnv &D = envs[i]; memset(&D, 0, sizeof(D));
+        if (!is_affine(E.light_to_world)) { set_error(ctx, "rt_scene_create: light transforms must be affine"); return -1; }
+        memcpy(D.l2w, E.light_to_world, 48);
+        D.width = E.width; D.height = E.height; D.nu = E.nu; D.nv = E.nv; D.marginal_int = E.marginal_int; D.world_radius = E.world_radius;
+        auto upf = [&](const float *src, size_t n, const float **dst) -> hipError_t {
+            DevBuf *b = new DevBuf; sc->d_texels.push_back(b);
+            hipError_t e = b->alloc(n * sizeof(float)); if (e != hipSuccess) return e;
+            *dst = (const float *)b->p;
+            return hipMemcpy(b->p, src, n * sizeof(float), hipMemcpyHostToDevice);
+        };
+        HIP_OK(upf(E.texels, 3 * (size_t)E.width * E.height, &D.texels)); HIP_OK(upf(E.func, (size_t)E.nu * E.nv, &D.func));
+        HIP_OK(upf(E.cdf, (size_t)E.nv * (E.nu + 1), &D.cdf)); HIP_OK(upf(E.func_int, (size_t)E.nv, &D.func_int));
+        HIP_OK(upf(E.marginal_cdf, (size_t)E.nv + 1, &D.marginal_cdf));
+    }
     std::vector<DevMaterial> mats((size_t)d->n_materials);
     for (int i = 0; i < d->n_materials; ++i) { mats[i].kind = d->materials[i].kind; memcpy(mats[i].tex, d->materials[i].tex, 16); mats[i].remap = d->materials[i].remap_roughness; }
 
@@ -1805,6 +1864,7 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     HIP_OK(up(sc->d_mats, mats.data(), mats.size() * sizeof(DevMaterial)));
     HIP_OK(up(sc->d_tex, tex.data(), tex.size() * sizeof(DevTexture)));
     HIP_OK(up(sc->d_lights, lights.data(), lights.size() * sizeof(DevLight)));
+    if (!envs.empty()) HIP_OK(up(sc->d_envs, envs.data(), envs.size() * sizeof(DevEnv)));
     // pair nodes: one 64-byte record per interior node with both children's boxes
     std::vector<int32_t> pairIndex(nn, -1);
     int n_pairs = 0;
@@ -1892,7 +1952,7 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     D.slot_uv = (const float *)sc->d_uv.p; D.spheres = (const float *)sc->d_spheres.p; D.slot_material = (const int *)sc->d_slot_mat.p;
     D.slot_light = (const int *)sc->d_slot_light.p; D.materials = (const DevMaterial *)sc->d_mats.p; D.textures = (const DevTexture *)sc->d_tex.p;
     D.lights = (const DevLight *)sc->d_lights.p; D.n_nodes = nn; D.n_slots = d->n_prims; D.n_lights = d->n_lights; D.pad = 0; D.n_materials = d->n_materials; D.n_textures = d->n_textures;
-    D.pairs = (const float4 *)sc->d_pairs.p; D.n_pairs = n_pairs;
+    D.pairs = (const float4 *)sc->d_pairs.p; D.n_pairs = n_pairs; D.envs = envs.empty() ? nullptr : (const DevEnv *)sc->d_envs.p;
     memcpy(D.root_box, sc->nodes[0].bmin, 12); memcpy(D.root_box + 3, sc->nodes[0].bmax, 12);
     D.root_info = childInfo(0);
     D.quads = quads_ok ? (const float4 *)sc->d_quads.p : nullptr; D.n_quads = quads_ok ? n_quads : 0; D.quad_stack_cap = quad_cap;
@@ -2074,6 +2134,11 @@ static bool shade_tables_in_lds(const DevScene &d) {
 template <int MAT>
 static void launch_shade(rt_scene *s, const RenderParams &rp, int bounce, const PathQueue &q, const PathQueue &qn, const HitBuf &hb, uint32_t cap,
                          uint32_t segcap, const ShadowQueue &sq, int nseg, bool fuse_shadow, float4 *lbuf, BounceStats *stats) {
+    if (s->dev.envs) {        // scenes with an infinite area light: tables in global memory, shadow rays through the shadow queue
+        hipLaunchKernelGGL((k_shade<MAT, 0, false, true>), dim3(nseg), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
+                           cap, segcap, sq, (BounceCounts *)s->d_counters.p, lbuf, stats);
+        return;
+    }
     const bool lds_tables = shade_tables_in_lds(s->dev);
     const size_t dyn = lds_tables ? shade_lds_bytes(s->dev) : 0;
     if (lds_tables && fuse_shadow)
@@ -2186,14 +2251,14 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     const int carry_from = env_int("RT_AMD_CARRY_FROM", 1);
     // shadow rays traced inside the shading kernels: scenes whose tree and tables both sit in LDS
     // (only while five blocks of the fused kernel still share a CU's 160 KB of LDS: 25.6 KB static + the scene's tables <= 32 KB)
-    const bool all_in_lds = lds_scene && round_pairs && !frame_old && shade_tables_in_lds(this_->dev) && shade_lds_bytes(this_->dev) <= 6400;
+    const bool all_in_lds = lds_scene && round_pairs && !frame_old && shade_tables_in_lds(this_->dev) && shade_lds_bytes(this_->dev) <= 6400 && !this_->dev.envs;
     // knob: shadow rays of LDS scenes through the shadow queue to k_shadow_carry (lanes refill as their any-hit walks end) instead of
     // inside the shading kernel, where a wave runs its 64 shadow rays to completion.  Measured on the Cornell frame: shading alone
     // 128 ms + k_shadow_carry 93 ms (round-based k_shadow: 106 ms) against 210 ms for the fused kernel, so fusing stays the default
     const int shadow_carry_from = (lds_scene && round_pairs && !frame_old) ? env_int("RT_AMD_SHADOW_CARRY_FROM", 1 << 30) : 1 << 30;
     const bool fuse_shadow = all_in_lds && shadow_carry_from > o->max_depth && env_int("RT_AMD_FUSE_SHADOW", 1) != 0;
     // the late, near-empty bounces of LDS scenes in one launch (k_finish)
-    const bool use_finish = (all_in_lds || (!lds_scene && round_quads && !frame_old)) && env_int("RT_AMD_FINISH", 1) != 0;
+    const bool use_finish = (all_in_lds || (!lds_scene && round_quads && !frame_old)) && !this_->dev.envs && env_int("RT_AMD_FINISH", 1) != 0;
     const int finish_chunks = env_int("RT_AMD_FINISH_CHUNKS", 2);
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
         int cur = std::min(spb, o->sample_end - s0);

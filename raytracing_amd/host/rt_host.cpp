@@ -370,6 +370,7 @@ void FlatScene::Bind() {
     desc.n_lights = (int32_t)lights.size(); desc.lights = lights.empty() ? nullptr : lights.data();
     desc.n_nodes = (int32_t)nodes.size(); desc.bvh_nodes = nodes.empty() ? nullptr : nodes.data();
     desc.prim_order = prim_order.empty() ? nullptr : prim_order.data();
+    desc.n_env_lights = (int32_t)env_lights.size(); desc.env_lights = env_lights.empty() ? nullptr : env_lights.data();
 }
 
 std::unique_ptr<FlatScene> FlattenScene(const Scene &scene) {
@@ -381,6 +382,14 @@ std::unique_ptr<FlatScene> FlattenScene(const Scene &scene) {
     std::map<const Light *, int> lightIndex;
     for (size_t i = 0; i < scene.lights.size(); ++i) lightIndex[scene.lights[i].get()] = (int)i;
     fs->lights.resize(scene.lights.size());
+    for (size_t i = 0; i < scene.lights.size(); ++i)
+        if (const InfiniteAreaLight *env = dynamic_cast<const InfiniteAreaLight *>(scene.lights[i].get())) {
+            rt_env_light e; env->Describe(&e);
+            rt_light &L = fs->lights[i];
+            L.prim = -1; L.kind = RT_LIGHT_INFINITE; L.env = (int32_t)fs->env_lights.size();
+            fs->env_lights.push_back(e);
+            FlatScene::EnvSource src; src.path = env->source; memcpy(src.L, env->scale, sizeof(src.L)); fs->env_sources.push_back(src);
+        }
     bool anyNormals = false;
     auto texOf = [&](const TextureBase *t) -> int {
         if (!t) return -1;
@@ -447,6 +456,15 @@ std::unique_ptr<FlatScene> FlattenScene(const Scene &scene) {
         int maxPrims = bvh ? bvh->maxPrimsInNode : 1, method = bvh ? (int)bvh->splitMethod : RT_SPLIT_MIDDLE;
         if (rt_bvh_build_ex(n, bounds.data(), maxPrims, method, fs->nodes.data(), &nn, fs->prim_order.data()) != 0) throw std::runtime_error("rt_bvh_build_ex failed");
         fs->nodes.resize(nn);
+        // InfiniteAreaLight::Preprocess (infinite.h:20-22, called by the Scene constructor, scene.cpp:6-13): the bounding sphere of
+        // the scene's world bound (Bounds3::BoundingSphere, geometry.h:801-804), which is the root node's box
+        for (rt_env_light &e : fs->env_lights) {
+            Point3f lo(fs->nodes[0].bmin[0], fs->nodes[0].bmin[1], fs->nodes[0].bmin[2]), hi(fs->nodes[0].bmax[0], fs->nodes[0].bmax[1], fs->nodes[0].bmax[2]);
+            Point3f c = (lo + hi) / 2;
+            bool inside = c.x >= lo.x && c.x <= hi.x && c.y >= lo.y && c.y <= hi.y && c.z >= lo.z && c.z <= hi.z;
+            e.world_center[0] = c.x; e.world_center[1] = c.y; e.world_center[2] = c.z;
+            e.world_radius = inside ? (c - hi).Length() : 0;
+        }
         fs->Bind();
     }
     return fs;

@@ -387,6 +387,28 @@ public:
     virtual ~Light() {}
 };
 class AreaLight : public Light {};
+
+// Radiance .hdr files (RGBE, run-length encoded or flat): the format the reference's InfiniteAreaLight reads through stbi_loadf
+// (infinite.cpp:16-18).  Floats are what that loader produces: mantissa byte * 2^(exponent - 136), three channels, and the rows
+// bottom-up when flipVertically is set (stbi_set_flip_vertically_on_load(true), infinite.cpp:17).
+bool ReadHDR(const std::string &path, int *width, int *height, std::vector<float> *rgb, bool flipVertically);
+bool WriteHDR(const std::string &path, int width, int height, const float *rgb);      // flat RGBE, rows top-down
+
+// The reference's InfiniteAreaLight (include/core/infinite.h, infinite.cpp:4-71): the constructor builds the radiance map
+// (L * texel, then r + Sqrt(r), infinite.cpp:20-28), its MIP pyramid, and the Distribution2D over luminance * sin(theta)
+// sampled at twice the map's resolution; Describe() hands all of it to rt_env_light.
+class InfiniteAreaLight : public Light {
+public:
+    InfiniteAreaLight(const Transform &LightToWorld, const Spectrum &power, int nSamples, const std::string &texmap);
+    void Describe(rt_env_light *out) const;      // world_center / world_radius are filled by FlattenScene (Preprocess, infinite.h:20-22)
+    Transform LightToWorld, WorldToLight;
+    std::string source; float scale[3];           // constructor arguments, kept for the test tooling
+    int width = 0, height = 0;                    // level 0 of the map
+    std::vector<float> texels;                    // width * height * 3
+    int nu = 0, nv = 0;
+    std::vector<float> func, cdf, funcInt, marginalCdf;
+    float marginalInt = 0;
+};
 class DiffuseAreaLight : public AreaLight {
 public:
     DiffuseAreaLight(const Transform &LightToWorld, const Spectrum &Le, int nSamples, const std::shared_ptr<Shape> &shape,
@@ -423,9 +445,12 @@ struct FlatScene {
     std::vector<rt_material> materials;
     std::vector<rt_texture> textures;
     std::vector<rt_light> lights;
+    std::vector<rt_env_light> env_lights;
     std::vector<rt_bvh_node> nodes;
     std::vector<std::shared_ptr<ImageData>> keepalive;
     std::vector<std::string> texture_sources;   // per texture: the file an image texture came from, else ""
+    struct EnvSource { std::string path; float L[3]; };
+    std::vector<EnvSource> env_sources;         // per infinite light: the .hdr file and the scale its constructor was given
     void Bind();   // point desc at the vectors
 };
 

@@ -74,7 +74,9 @@ void AddCeilingLight(BuiltScene &bs, std::vector<std::shared_ptr<Primitive>> &pr
 }
 
 // plastic: the short cube gets a PlasticMaterial (not in the reference's scene; exercises the two-lobe BSDF of material.cpp:32-49)
-void BuildCornell(BuiltScene &bs, bool plastic = false) {
+// env: an InfiniteAreaLight (include/core/infinite.h) joins the two ceiling triangles in scene.lights; the room's front is open, so
+// its light reaches the inside (no shipped scene constructs one)
+void BuildCornell(BuiltScene &bs, bool plastic = false, const std::string &envMap = "") {
     std::vector<std::shared_ptr<Primitive>> prims; std::vector<std::shared_ptr<Light>> lights;
     AddCeilingLight(bs, prims, lights, Matte(Spectrum(1.0f, 1.0f, 1.0f)), 20.f);
     std::shared_ptr<Material> mirror = make_shared<MirrorMaterial>(Const(Spectrum(1.f)));
@@ -90,6 +92,8 @@ void BuildCornell(BuiltScene &bs, bool plastic = false) {
     // the tall block: its "top" face sits at y = h while the sides reach 2h (RayTracing.cpp:166-167)
     auto block = BoxTriangles(bs, Translate(Vector3f(2.7f, 0.f, 1.0f)) * RotateY(-15) * Transform(), 12, h, h, h * 2);
     for (int i = 0; i < 12; ++i) prims.push_back(make_shared<GeometricPrimitive>(block[i], i < 10 ? mwhite : mirror, nullptr));
+    if (!envMap.empty())
+        lights.push_back(make_shared<InfiniteAreaLight>(RotateY(30) * RotateX(-90), Spectrum(1.5f, 1.2f, 1.0f), 1, envMap));
     bs.scene = make_shared<Scene>(make_shared<BVHAccel>(prims), lights);
     bs.lookat = LookAt(Point3f(2.5f, 2.5f, 11.8f), Point3f(2.5f, 2.5f, 0.0f), Vector3f(0.0f, 1.0f, 0.0f));
 }
@@ -163,7 +167,9 @@ void AddSphere(BuiltScene &bs, std::vector<std::shared_ptr<Primitive>> &prims, c
 
 // variant 2 ("spheres3"): the extended scene plus a sphere whose texture is a 300 x 200 PNG (not powers of two: resampled to
 // 512 x 256 on load, mipmap.h:70-121) looked up through UVMapping2D(2, 3, 0.25, 0.5) (texture.cpp:5-13)
-void BuildSpheres(BuiltScene &bs, bool extended, const std::string &assets, bool oddTexture = false) {
+// envOnly ("spheres_env"): the scene's only light is an InfiniteAreaLight, so there is no sky term (integrator.cpp:249-254 needs
+// an empty light list) and escaped rays carry nothing; all light arrives through next-event estimation.
+void BuildSpheres(BuiltScene &bs, bool extended, const std::string &assets, bool oddTexture = false, bool envOnly = false) {
     srand(1);   // glibc's default seed, so repeated builds in one process give the same layout
     std::vector<std::shared_ptr<Primitive>> prims;
     AddSphere(bs, prims, Vector3f(0.f, -1000.f, 0.f), 1000.0, Matte(Spectrum(0.5, 0.5, 0.5)));
@@ -198,6 +204,7 @@ void BuildSpheres(BuiltScene &bs, bool extended, const std::string &assets, bool
         AddSphere(bs, prims, Vector3f(6.5f, 0.8f, 2.2f), 0.8, make_shared<MatteMaterial>(pat, ConstF(0.0f)));
     }
     std::vector<std::shared_ptr<Light>> lights;
+    if (envOnly) lights.push_back(make_shared<InfiniteAreaLight>(RotateX(-90), Spectrum(1.f), 1, assets + "/env_48x20.hdr"));
     bs.scene = make_shared<Scene>(make_shared<BVHAccel>(prims), lights);
     bs.lookat = LookAt(Point3f(13, 2, 3), Point3f(0.f, 0.f, 0.f), Vector3f(0.0f, 1.0f, 0.0f));
 }
@@ -272,6 +279,8 @@ rth_scene *rth_scene_build(const char *name, const char *assets_dir, int64_t par
         else if (nm == "spheres2") BuildSpheres(h->b, true, assets);
         else if (nm == "spheres3") BuildSpheres(h->b, true, assets, true);
         else if (nm == "cornell_metal") BuildCornellMetal(h->b);
+        else if (nm == "cornell_env") BuildCornell(h->b, false, assets + "/env_48x20.hdr");
+        else if (nm == "spheres_env") BuildSpheres(h->b, true, assets, false, true);
         else if (nm == "helmet") BuildHelmet(h->b, assets);
         else if (nm == "helmet_glb") BuildHelmet(h->b, assets, "/DamagedHelmet/glTF-Binary/DamagedHelmet.glb");   // the same model as one binary container
         else if (nm == "soup") BuildSoup(h->b, param);
@@ -285,6 +294,13 @@ const rt_scene_desc *rth_scene_desc(rth_scene *h) { return &h->b.flat->desc; }
 const char *rth_scene_texture_source(rth_scene *h, int index) {
     const std::vector<std::string> &src = h->b.flat->texture_sources;
     return (index >= 0 && index < (int)src.size()) ? src[index].c_str() : "";
+}
+// Constructor arguments of infinite light `index`: its .hdr file and scale (L receives three floats).
+const char *rth_scene_env_source(rth_scene *h, int index, float *L) {
+    const auto &src = h->b.flat->env_sources;
+    if (index < 0 || index >= (int)src.size()) return "";
+    if (L) memcpy(L, src[index].L, sizeof(src[index].L));
+    return src[index].path.c_str();
 }
 int rth_scene_camera(rth_scene *h, int width, int height, rt_camera *out) {
     Transform c2w = Inverse(h->b.lookat);
@@ -315,6 +331,16 @@ int rth_model_probe(const char *path, int apply_node_transforms, int *n_tris, fl
     }
     *n_tris = n;
     if (names && names_cap > 0) snprintf(names, (size_t)names_cap, "%s|%s", ML.diffTexName.empty() ? "" : ML.diffTexName[0].c_str(), ML.specTexName.empty() ? "" : ML.specTexName[0].c_str());
+    return 0;
+}
+// Radiance .hdr files: write w*h*3 floats (rows top-down, flat RGBE); read back what the reference's loader would hand its
+// InfiniteAreaLight (rows bottom-up when flip is set).  Call rth_read_hdr with out == nullptr for the size.  0 = ok.
+int rth_write_hdr(const char *path, int w, int h, const float *rgb) { return (path && rgb && WriteHDR(path, w, h, rgb)) ? 0 : -1; }
+int rth_read_hdr(const char *path, int flip, int *w, int *h, float *out) {
+    if (!path || !w || !h) return -1;
+    std::vector<float> rgb;
+    try { if (!ReadHDR(path, w, h, &rgb, flip != 0)) return -1; } catch (std::exception &e) { g_error = e.what(); return -1; }
+    if (out) memcpy(out, rgb.data(), rgb.size() * sizeof(float));
     return 0;
 }
 // Decode a PNG / JPEG held in memory.  Call with out == nullptr for the size, then with a w*h*3 buffer.  0 = ok.

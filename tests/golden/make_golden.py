@@ -9,6 +9,7 @@ ray batches and probe points, and stores what the reference computed:
   ref_rays_<scene>.npz     ray batches (camera / diffuse bounce / shadow segments / random) with the reference's
                            closest-hit primitive, t, (u,v) and any-hit answer
   ref_probe_<scene>.npz    interaction + BSDF known answers at probe hits (p, n, wo, uv, dpdu, f, Sample_f)
+  ref_env_<scene>.npz      InfiniteAreaLight: radiance map, Distribution2D tables, bounding sphere, Sample_Li known answers
   ref_camera.npz           PerspectiveCamera::GenerateRay known answers
   ref_transform.npz        Transform composition known answers (matrices, inverses, transformed points)
   ref_img_<scene>_*.npy    float radiance sums rendered by PathIntegrator::Li_re with the reference's
@@ -128,6 +129,18 @@ def golden_for_scene(name, n_rays, img_specs, probe_n=512):
     run("probe", sbin, ppath, qpath)
     pout = np.fromfile(qpath, dtype=np.float32).reshape(probe_n, 26)
     np.savez_compressed(os.path.join(GOLD, "ref_probe_%s.npz" % name), probes=probes, out=pout)
+    # --- infinite light: the tables its constructor and Preprocess build, and Sample_Li known answers
+    if scene.desc.n_env_lights:
+        epath = os.path.join(TMP, name + ".env")
+        run("env", sbin, epath)
+        a = np.fromfile(epath, dtype=np.float32)
+        w_, h_, nu, nv = (int(v) for v in a[:4]); pos = [4]
+
+        def take(n):
+            v = a[pos[0]:pos[0] + n].copy(); pos[0] += n; return v
+        np.savez_compressed(os.path.join(GOLD, "ref_env_%s.npz" % name), size=np.array([w_, h_, nu, nv]), texels=take(w_ * h_ * 3), func=take(nu * nv),
+                            cdf=take(nv * (nu + 1)), func_int=take(nv), marginal_cdf=take(nv + 1), marginal_int=take(1), world_center=take(3),
+                            world_radius=take(1), sample_li=take(256 * 15).reshape(256, 15))
     # --- images
     for (w, h, sx, sy, seeds) in img_specs:
         cpath = os.path.join(TMP, "%s_%d.cam" % (name, w))
@@ -226,6 +239,11 @@ if __name__ == "__main__":
     # a 300 x 200 texture (resampled to powers of two by the reference itself) behind UVMapping2D(2, 3, 0.25, 0.5)
     if not only or "spheres3" in only:
         golden_for_scene("spheres3", 2048, [(96, 96, 8, 8, [A, B])])
+    # InfiniteAreaLight next to area lights (Cornell box with its open front) and as a scene's only light
+    if not only or "cornell_env" in only:
+        golden_for_scene("cornell_env", 2048, [(100, 100, 16, 16, [A, B])])
+    if not only or "spheres_env" in only:
+        golden_for_scene("spheres_env", 2048, [(96, 96, 20, 20, [A, B])])      # a small sun in the map: 400 spp bring the two seeds within 0.2 %
     if not only or "sphere1" in only:
         golden_for_scene("sphere1", 4096, [(64, 64, 4, 4, [A, B])])
     if not only or "spheres2" in only:

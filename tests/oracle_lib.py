@@ -42,6 +42,7 @@ def lib():
         L.orc_philox.argtypes = [u32p, C.c_uint32, C.c_uint32, u32p]
         L.orc_film_sample.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, f32p, f32p]
         L.orc_texture_eval.argtypes = [vp, C.c_int, C.c_float, C.c_float, f32p]
+        L.orc_env_sample.argtypes = [vp, C.c_int, f32p, C.c_float, C.c_float, f32p]
         L.orc_interaction.argtypes = [vp, f32p, f32p, C.c_float, f32p]
         L.orc_bsdf_probe.argtypes = [vp, f32p, f32p, f32p, C.c_float, C.c_float, f32p]
         _lib = L
@@ -111,6 +112,12 @@ class OracleScene:
         out = np.zeros(11, np.float32)
         prim = lib().orc_bsdf_probe(self._p, capi.fptr(o), capi.fptr(d), capi.fptr(wi), u0, u1, capi.fptr(out))
         return prim, out
+
+    def env_sample(self, env, p, u0, u1):
+        p = np.ascontiguousarray(p, np.float32); out = np.zeros(10, np.float32)
+        if lib().orc_env_sample(self._p, env, capi.fptr(p), u0, u1, capi.fptr(out)) != 0:
+            raise ValueError("no such infinite light")
+        return out
 
     def texture_eval(self, tex, u, v):
         out = np.zeros(3, np.float32)

@@ -13,6 +13,8 @@ CAMERAS = {   # eye, look, up of the reference's scene functions (RayTracing.cpp
     "spheres2": ((13, 2, 3), (0, 0, 0), (0, 1, 0)),
     "spheres3": ((13, 2, 3), (0, 0, 0), (0, 1, 0)),
     "cornell_metal": ((2.5, 2.5, 11.8), (2.5, 2.5, 0.0), (0, 1, 0)),
+    "cornell_env": ((2.5, 2.5, 11.8), (2.5, 2.5, 0.0), (0, 1, 0)),
+    "spheres_env": ((13, 2, 3), (0, 0, 0), (0, 1, 0)),
     "helmet": ((3.5, 3.2, 1.5), (2.0, 2.3, 2.8), (0, 1, 0)),
 }
 
@@ -66,7 +68,13 @@ def dump_scene(scene, path, tmp):
         out.append(struct.pack("<3i3f4fi", t.kind, t.width, t.height, *list(t.value), t.su, t.sv, t.du, t.dv, len(png)) + png)
     for i in range(d.n_lights):
         L = d.lights[i]
-        out.append(struct.pack("<i3fifi", L.prim, *list(L.Le), L.two_sided, L.area, L.flip_normal))
+        out.append(struct.pack("<i3fif3i", L.prim, *list(L.Le), L.two_sided, L.area, L.flip_normal, L.kind, L.env))
+    # infinite lights: what the reference's constructor takes (transform, scale, .hdr file); it builds its tables itself
+    out.append(struct.pack("<i", d.n_env_lights))
+    for i in range(d.n_env_lights):
+        e = d.env_lights[i]
+        hdr, scale = scene.env_source(i)
+        out.append(struct.pack("<35f", *list(e.light_to_world), *list(e.world_to_light), *scale) + struct.pack("<i", len(hdr.encode())) + hdr.encode())
     with open(path, "wb") as f:
         f.write(b"".join(out))
 

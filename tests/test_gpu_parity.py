@@ -10,7 +10,7 @@ import pytest
 import raytracing_amd as ra
 
 pytestmark = pytest.mark.gpu
-SCENES = ["cornell", "cornell_plastic", "cornell_metal", "sphere1", "spheres2", "spheres3", "helmet"]
+SCENES = ["cornell", "cornell_plastic", "cornell_metal", "cornell_env", "sphere1", "spheres2", "spheres3", "spheres_env", "helmet"]
 
 
 def _rel_close(img, ref, tol):
@@ -194,8 +194,8 @@ def test_trace_edge_cases(device_scene):
     assert prim[0] == -1
 
 
-@pytest.mark.parametrize("name,w,sx", [("cornell", 96, 4), ("cornell_plastic", 96, 4), ("cornell_metal", 96, 4), ("sphere1", 96, 4), ("spheres2", 96, 4),
-                                       ("spheres3", 96, 4), ("helmet", 96, 4)])
+@pytest.mark.parametrize("name,w,sx", [("cornell", 96, 4), ("cornell_plastic", 96, 4), ("cornell_metal", 96, 4), ("cornell_env", 96, 4), ("sphere1", 96, 4),
+                                       ("spheres2", 96, 4), ("spheres3", 96, 4), ("spheres_env", 96, 4), ("helmet", 96, 4)])
 def test_render_matches_oracle_per_pixel(name, w, sx, device_scene, oracle_scene, host_scene):
     """Same sampler on both sides: identical ray counts (up to a handful of paths whose branch flips on a last-bit libm
     difference) and per-pixel sums equal within 2e-3 relative for all but a few such pixels."""
@@ -211,8 +211,8 @@ def test_render_matches_oracle_per_pixel(name, w, sx, device_scene, oracle_scene
     assert np.all(np.abs(img.mean(axis=(0, 1)) / ref.mean(axis=(0, 1)) - 1) < 2e-3)
 
 
-@pytest.mark.parametrize("name,w,spp", [("cornell", 100, 256), ("cornell_plastic", 100, 256), ("cornell_metal", 100, 256), ("spheres2", 96, 64), ("spheres3", 96, 64),
-                                        ("helmet", 96, 64), ("sphere1", 64, 16)])
+@pytest.mark.parametrize("name,w,spp", [("cornell", 100, 256), ("cornell_plastic", 100, 256), ("cornell_metal", 100, 256), ("cornell_env", 100, 256), ("spheres2", 96, 64),
+                                        ("spheres3", 96, 64), ("spheres_env", 96, 400), ("helmet", 96, 64), ("sphere1", 64, 16)])
 def test_render_within_reference_noise_floor(name, w, spp, device_scene, host_scene, gold_dir):
     """Against images rendered by the reference's PathIntegrator::Li_re with its own sampler: per-channel mean within
     0.5 % and RMSE (vs the mean of the reference's two seeds) below the reference's own seed-A-vs-seed-B RMSE."""
@@ -304,7 +304,8 @@ def test_headline_frame_against_reference_and_shipped_image(device_scene, host_s
     assert np.all(np.abs(ratio - 1) < 0.03), ratio
 
 
-@pytest.mark.parametrize("name,w", [("cornell", 200), ("cornell_plastic", 120), ("cornell_metal", 120), ("helmet", 160), ("spheres2", 160)])
+@pytest.mark.parametrize("name,w", [("cornell", 200), ("cornell_plastic", 120), ("cornell_metal", 120), ("cornell_env", 120), ("helmet", 160), ("spheres2", 160),
+                                    ("spheres_env", 120)])
 def test_frame_walks_give_identical_images(name, w, device_scene, host_scene, monkeypatch):
     """The frame kernels have three walks (round-based over pair/quad records, persistent lanes, round-based over plain
     nodes) and several ways of dividing and fusing the work.  Traversal is bit-exact in all of them and every sample is a pure

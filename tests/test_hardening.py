@@ -214,3 +214,64 @@ def test_jpeg_with_corrupt_tables_fails_cleanly():
     data[pos + 5:pos + 9] = b"\xff\xff\xff\xff"
     with pytest.raises(ValueError):
         ra.decode_image(bytes(data))
+
+
+def test_infinite_light_descriptions_are_checked(host_scene):
+    hs = host_scene("cornell_env")
+    assert _check(hs.desc)[0] == 0
+    d = _copy(hs.desc)
+    lights = (capi.Light * d.n_lights)(*[hs.desc.lights[i] for i in range(d.n_lights)])
+    lights[2].env = 3
+    d.lights = C.cast(lights, C.POINTER(capi.Light))
+    assert "infinite light" in _check(d)[1]
+    lights[2].env = 0; lights[2].kind = 9
+    assert "light kind" in _check(d)[1]
+    d = _copy(hs.desc)
+    envs = (capi.EnvLight * 1)(hs.desc.env_lights[0])
+    envs[0].cdf = None
+    d.env_lights = C.cast(envs, C.POINTER(capi.EnvLight))
+    assert "NULL table" in _check(d)[1]
+    envs[0].cdf = hs.desc.env_lights[0].cdf; envs[0].nu = 0
+    assert "empty" in _check(d)[1]
+    d = _copy(hs.desc); d.env_lights = None
+    assert "env_lights" in _check(d)[1]
+
+
+def test_hdr_reader_flat_and_run_length_encoded(tmp_path):
+    """Radiance .hdr as stb_image's loader reads it: value = mantissa byte * 2^(exponent - 136), rows flipped on request; a
+    run-length encoded file (runs and literal spans per channel) decodes to the same floats as the flat one."""
+    rng = np.random.default_rng(4)
+    h, w = 9, 40
+    img = (rng.random((h, w, 3)) ** 4 * 50).astype(np.float32); img[2, 5:30] = [1.5, 0.25, 0.0]; img[3] = 0
+    flat = tmp_path / "flat.hdr"
+    ra.write_hdr(flat, img)
+    got = ra.read_hdr(flat)
+    raw = open(flat, "rb").read()
+    rgbe = np.frombuffer(raw[raw.index(b"+X %d\n" % w) + len(b"+X %d\n" % w):], np.uint8).reshape(h, w, 4)
+    want = rgbe[:, :, :3].astype(np.float32) * np.where(rgbe[:, :, 3:] > 0, np.ldexp(np.float32(1), rgbe[:, :, 3:].astype(int) - 136), 0).astype(np.float32)
+    assert np.array_equal(got, want) and np.abs(got - img).max() <= img.max() / 128
+    assert np.array_equal(ra.read_hdr(flat, flip=True), want[::-1])
+    # the same pixels, run-length encoded the way Radiance writes them
+    out = bytearray(raw[:raw.index(b"+X %d\n" % w) + len(b"+X %d\n" % w)])
+    for y in range(h):
+        out += bytes([2, 2, w >> 8, w & 255])
+        for c in range(4):
+            row = rgbe[y, :, c].tolist(); i = 0
+            while i < w:
+                run = 1
+                while i + run < w and run < 127 and row[i + run] == row[i]:
+                    run += 1
+                if run >= 3:
+                    out += bytes([128 + run, row[i]]); i += run
+                else:
+                    j = i
+                    while j < w and j - i < 128 and not (j + 2 < w and row[j] == row[j + 1] == row[j + 2]):
+                        j += 1
+                    j = max(j, i + 1)
+                    out += bytes([j - i]) + bytes(row[i:j]); i = j
+    rle = tmp_path / "rle.hdr"
+    rle.write_bytes(bytes(out))
+    assert np.array_equal(ra.read_hdr(rle), want)
+    (tmp_path / "bad.hdr").write_bytes(raw[:40])
+    with pytest.raises(RuntimeError):
+        ra.read_hdr(tmp_path / "bad.hdr")
