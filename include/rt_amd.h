@@ -71,7 +71,10 @@ enum {
     RT_MAT_METAL      = 3,  /* tex[0]=eta tex[1]=k tex[2]=urough tex[3]=vrough, flag remap
                                (urough/vrough already resolved against `roughness`) material.cpp:51-67 */
     RT_MAT_PLASTIC    = 4,  /* tex[0]=Kd tex[1]=Ks tex[2]=roughness, flag remap material.cpp:32-49 */
-    RT_MAT_METALROUGH = 5   /* tex[0]=base_color tex[1]=metalroughness or -1    material.cpp:69-82 */
+    RT_MAT_METALROUGH = 5,  /* tex[0]=base_color tex[1]=metalroughness or -1    material.cpp:69-82 */
+    RT_MAT_ROUGHGLASS = 6   /* tex[0]=Kr tex[1]=Kt tex[2]=index tex[3]=roughness, flag remap.  No material of the reference builds
+                               it: this is the carrier of its MicrofacetTransmission lobe (reflection.cpp:311-355), paired, as in
+                               pbrt's glass, with MicrofacetReflection under FresnelDielectric(1, index) (reflection.cpp:241-266) */
 };
 
 typedef struct rt_material {

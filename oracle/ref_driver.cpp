@@ -43,6 +43,7 @@
 #include "core/interaction.h"
 #include "core/light.h"
 #include "core/material.h"
+#include "core/microfacet.h"
 #include "core/reflection.h"
 #include "core/scene.h"
 #include "core/sphere.h"
@@ -60,6 +61,26 @@ struct LinearBVHNode {
     uint16_t nPrimitives; uint8_t axis; uint8_t pad[1];
 };
 static_assert(sizeof(LinearBVHNode) == 32, "LinearBVHNode layout");
+
+// The reference defines MicrofacetTransmission (reflection.cpp:311-355) but none of its materials adds it to a BSDF.  This
+// material — the driver's, built from the reference's own BxDF classes the way pbrt's glass assembles them — does, so that the
+// lobe can be exercised through the reference's BSDF / integrator code.
+class RoughGlassTestMaterial : public Material {
+public:
+    RoughGlassTestMaterial(const std::shared_ptr<Texture<Spectrum>> &Kr, const std::shared_ptr<Texture<Spectrum>> &Kt, const std::shared_ptr<Texture<Float>> &index,
+                           const std::shared_ptr<Texture<Float>> &rough, bool remap) : Kr(Kr), Kt(Kt), index(index), rough(rough), remap(remap) {}
+    void ComputeScatteringFunctions(SurfaceInteraction *si, TransportMode mode, bool allowMultipleLobes) const override {
+        Float eta = index->Evaluate(*si), r = rough->Evaluate(*si);
+        Spectrum R = Kr->Evaluate(*si).Clamp(), T = Kt->Evaluate(*si).Clamp();
+        si->bsdf = new BSDF(*si, eta);
+        if (R.IsBlack() && T.IsBlack()) return;
+        if (remap) r = TrowbridgeReitzDistribution::RoughnessToAlpha(r);
+        if (!R.IsBlack()) si->bsdf->Add(new MicrofacetReflection(R, new TrowbridgeReitzDistribution(r, r), new FresnelDielectric(1.f, eta)));
+        if (!T.IsBlack()) si->bsdf->Add(new MicrofacetTransmission(T, new TrowbridgeReitzDistribution(r, r), 1.f, eta, mode));
+    }
+private:
+    std::shared_ptr<Texture<Spectrum>> Kr, Kt; std::shared_ptr<Texture<Float>> index, rough; bool remap;
+};
 
 // ------------------------------------------------------------- scene dump --
 struct Reader {
@@ -114,6 +135,7 @@ static void LoadScene(const std::string &path, RefScene &rs) {
         case RT_MAT_GLASS: materials[i] = std::make_shared<GlassMaterial>(texS[t[0]], texS[t[1]], texF[t[2]]); break;
         case RT_MAT_METAL: materials[i] = std::make_shared<MetalMaterial>(texS[t[0]], texS[t[1]], texF[t[2]], texF[t[2]], texF[t[3]], remap); break;
         case RT_MAT_PLASTIC: materials[i] = std::make_shared<PlasticMaterial>(texS[t[0]], texS[t[1]], texF[t[2]], remap); break;
+        case RT_MAT_ROUGHGLASS: materials[i] = std::make_shared<RoughGlassTestMaterial>(texS[t[0]], texS[t[1]], texF[t[2]], texF[t[3]], remap); break;
         case RT_MAT_METALROUGH: materials[i] = std::make_shared<MetalRoughnessMaterial>(texS[t[0]], t[1] >= 0 ? texS[t[1]] : nullptr); break;
         default: fprintf(stderr, "bad material\n"); exit(2);
         }

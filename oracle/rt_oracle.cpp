@@ -569,7 +569,7 @@ RGB EvalTexture(const Scene &sc, int tex, Float u, Float v) {
 
 // ------------------------------------------------------------------- BSDF --
 enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_ALL = 31 };
-enum { LOBE_LAMBERT, LOBE_SPEC_REFL, LOBE_SPEC_TRANS, LOBE_MICRO_CONDUCTOR, LOBE_MICRO_DIELECTRIC, LOBE_METALROUGH };
+enum { LOBE_LAMBERT, LOBE_SPEC_REFL, LOBE_SPEC_TRANS, LOBE_MICRO_CONDUCTOR, LOBE_MICRO_DIELECTRIC, LOBE_METALROUGH, LOBE_MICRO_TRANS };
 
 inline Float CosTheta(V3 w) { return w.z; }
 inline Float Cos2Theta(V3 w) { return w.z * w.z; }
@@ -750,11 +750,35 @@ RGB LobeF(const Lobe &l, V3 wo, V3 wi) {
         kD = kD * (Float)(1.0 - l.metallic);
         return specular + kD * l.R * InvPi;
     }
+    case LOBE_MICRO_TRANS: {                // MicrofacetTransmission::f, reflection.cpp:311-334 (TransportMode::Radiance)
+        if (SameHemisphere(wo, wi)) return rgb1(0.f);
+        Float cosThetaO = CosTheta(wo), cosThetaI = CosTheta(wi);
+        if (cosThetaI == 0 || cosThetaO == 0) return rgb1(0.f);
+        Float eta = CosTheta(wo) > 0 ? (l.etaB / l.etaA) : (l.etaA / l.etaB);
+        V3 wh = Normalize(wo + wi * eta);
+        if (wh.z < 0) wh = -wh;
+        if (Dot(wo, wh) * Dot(wi, wh) > 0) return rgb1(0.f);
+        RGB F = rgb1(FrDielectric(Dot(wo, wh), l.etaA, l.etaB));
+        Float sqrtDenom = Dot(wo, wh) + eta * Dot(wi, wh);
+        Float factor = 1 / eta;
+        return (rgb1(1.f) - F) * l.R *
+               std::abs(l.distrib.D(wh) * l.distrib.G(wo, wi) * eta * eta * AbsDot(wi, wh) * AbsDot(wo, wh) * factor * factor /
+                        (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
+    }
     default: return rgb1(0.f);              // specular lobes: reflection.h:203-205,226-228
     }
 }
 Float LobePdf(const Lobe &l, V3 wo, V3 wi) {
     switch (l.kind) {
+    case LOBE_MICRO_TRANS: {                // MicrofacetTransmission::Pdf, reflection.cpp:346-355
+        if (SameHemisphere(wo, wi)) return 0;
+        Float eta = CosTheta(wo) > 0 ? (l.etaB / l.etaA) : (l.etaA / l.etaB);
+        V3 wh = Normalize(wo + wi * eta);
+        if (Dot(wo, wh) * Dot(wi, wh) > 0) return 0;
+        Float sqrtDenom = Dot(wo, wh) + eta * Dot(wi, wh);
+        Float dwh_dwi = std::abs((eta * eta * Dot(wi, wh)) / (sqrtDenom * sqrtDenom));
+        return l.distrib.Pdf(wo, wh) * dwh_dwi;
+    }
     case LOBE_LAMBERT: return SameHemisphere(wo, wi) ? AbsCosTheta(wi) * InvPi : 0;  // reflection.cpp:107-109
     case LOBE_MICRO_CONDUCTOR: case LOBE_MICRO_DIELECTRIC: case LOBE_METALROUGH: {    // reflection.cpp:262-266,296-300
         if (!SameHemisphere(wo, wi)) return 0;
@@ -786,6 +810,15 @@ RGB LobeSample(const Lobe &l, V3 wo, V3 *wi, Float u0, Float u1, Float *pdf) {
         RGB ft = l.R * (rgb1(1.) - rgb1(FrDielectric(CosTheta(*wi), l.etaA, l.etaB)));
         ft = ft * ((etaI * etaI) / (etaT * etaT));
         return ft / AbsCosTheta(*wi);
+    }
+    case LOBE_MICRO_TRANS: {                  // MicrofacetTransmission::Sample_f, reflection.cpp:336-344
+        if (wo.z == 0) return rgb1(0.);
+        V3 wh = l.distrib.Sample_wh(wo, u0, u1);
+        if (Dot(wo, wh) < 0) return rgb1(0.);
+        Float eta = CosTheta(wo) > 0 ? (l.etaA / l.etaB) : (l.etaB / l.etaA);
+        if (!Refract(wo, wh, eta, wi)) return rgb1(0.);
+        *pdf = LobePdf(l, wo, *wi);
+        return LobeF(l, wo, *wi);
     }
     default: {                                // reflection.cpp:251-260,286-294
         if (wo.z == 0) return rgb1(0.);
@@ -892,6 +925,22 @@ void ComputeScatteringFunctions(const Scene &sc, const SurfaceInteraction &si, B
         if (m.remap_roughness) { uRough = RoughnessToAlpha(uRough); vRough = RoughnessToAlpha(vRough); }
         l.kind = LOBE_MICRO_CONDUCTOR; l.type = BSDF_REFLECTION | BSDF_GLOSSY; l.R = rgb1(1.);
         l.eta = tex(0); l.k = tex(1); l.distrib = MakeTR(uRough, vRough); b->lobes[b->n++] = l;
+        break;
+    }
+    case RT_MAT_ROUGHGLASS: {      // no material of the reference: its two rough dielectric lobes, assembled as pbrt's glass does
+        Float eta = tex(2)[0], rough = tex(3)[0];
+        RGB R = ClampRGB(tex(0)), T = ClampRGB(tex(1));
+        b->eta = eta;
+        if (IsBlack(R) && IsBlack(T)) break;
+        if (m.remap_roughness) rough = RoughnessToAlpha(rough);
+        if (!IsBlack(R)) {
+            Lobe r = l; r.kind = LOBE_MICRO_DIELECTRIC; r.type = BSDF_REFLECTION | BSDF_GLOSSY; r.R = R; r.etaA = 1.f; r.etaB = eta;
+            r.distrib = MakeTR(rough, rough); b->lobes[b->n++] = r;
+        }
+        if (!IsBlack(T)) {
+            l.kind = LOBE_MICRO_TRANS; l.type = BSDF_TRANSMISSION | BSDF_GLOSSY; l.R = T; l.etaA = 1.f; l.etaB = eta;
+            l.distrib = MakeTR(rough, rough); b->lobes[b->n++] = l;
+        }
         break;
     }
     case RT_MAT_METALROUGH: {

@@ -520,6 +520,6 @@ struct TRDist {
 };
 __device__ __forceinline__ float roughness_to_alpha(float roughness) {   // microfacet.h:74-78
     roughness = fmaxf(roughness, 1e-3f);
-    float x = logf(roughness);
+    float x = (float)log((double)roughness);      // the device logf is a few ulp off the host library's; a rounded double log is not
     return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
 }

@@ -37,7 +37,7 @@
         if (e_ != hipSuccess) { set_error(ctx_of(this_), std::string(#expr) + ": " + hipGetErrorString(e_)); return -2; } \
     } while (0)
 
-#define RT_NUM_CLASSES 6
+#define RT_NUM_CLASSES 7
 #define RT_BATCH_STACK 32       // LDS ring depth of the batch trace kernels (deep trees)
 #define RT_SEG_BLOCKS 1280      // most queue segments = largest grid of the wavefront kernels (five blocks per CU)
 #define RT_SEG_PER_THREAD (RT_SEG_BLOCKS / RT_BLOCK)
@@ -584,12 +584,14 @@ __device__ __forceinline__ F3 to_world(const SurfacePoint &sp, F3 v) {
 // One scattering lobe of the hit's BSDF (the shipped materials have exactly one, material.cpp:5-82).
 struct Lobe {
     int kind;        // 0 none, 1 Lambert, 2 specular reflection, 3 specular transmission, 4 microfacet conductor, 5 metal-roughness,
-                     // 6 microfacet with dielectric Fresnel (etaA = 1.5, etaB = 1: PlasticMaterial, material.cpp:44-47)
+                     // 6 microfacet reflection with dielectric Fresnel (etaA, etaB) = (1.5, 1) for PlasticMaterial, material.cpp:44-47,
+                     // 7 microfacet transmission between etaA and etaB (reflection.cpp:311-355)
     F3 R, eta, k;
-    float etaB, metallic;
+    float etaA, etaB, metallic;
     TRDist dist;
 };
 __device__ __forceinline__ bool lobe_is_specular(int kind) { return kind == 2 || kind == 3; }
+__device__ __forceinline__ bool lobe_transmits(int kind) { return kind == 3 || kind == 7; }
 
 // BxDF::f in the local frame: reflection.cpp:135-137, 241-249, 268-284.
 __device__ __forceinline__ F3 lobe_f(const Lobe &l, F3 wo, F3 wi) {
@@ -610,7 +612,7 @@ __device__ __forceinline__ F3 lobe_f(const Lobe &l, F3 wo, F3 wi) {
             return cdiv(f3(((l.R.x * Dv) * Gv) * F.x, ((l.R.y * Dv) * Gv) * F.y, ((l.R.z * Dv) * Gv) * F.z), den);
         }
         if (l.kind == 6) {
-            float F = fr_dielectric(c, 1.5f, 1.f);
+            float F = fr_dielectric(c, l.etaA, l.etaB);
             float den = 4 * cosI * cosO;
             return cdiv(f3(((l.R.x * Dv) * Gv) * F, ((l.R.y * Dv) * Gv) * F, ((l.R.z * Dv) * Gv) * F), den);
         }
@@ -627,7 +629,44 @@ __device__ __forceinline__ F3 lobe_f(const Lobe &l, F3 wo, F3 wi) {
         F3 kD = f3((1.0f - F.x) * km, (1.0f - F.y) * km, (1.0f - F.z) * km);
         return f3(spec.x + (kD.x * l.R.x) * RT_INV_PI, spec.y + (kD.y * l.R.y) * RT_INV_PI, spec.z + (kD.z * l.R.z) * RT_INV_PI);
     }
+    if (l.kind == 7) {                                                   // MicrofacetTransmission::f, Radiance mode
+        if (same_hemisphere(wo, wi)) return f3(0.f, 0.f, 0.f);
+        float cosO = wo.z, cosI = wi.z;
+        if (cosI == 0 || cosO == 0) return f3(0.f, 0.f, 0.f);
+        float eta = wo.z > 0 ? (l.etaB / l.etaA) : (l.etaA / l.etaB);
+        F3 wh = normalize3(wo + eta * wi);
+        if (wh.z < 0) wh = -wh;
+        float dwo = dot3(wo, wh), dwi = dot3(wi, wh);
+        if (dwo * dwi > 0) return f3(0.f, 0.f, 0.f);
+        float Fm = 1.f - fr_dielectric(dwo, l.etaA, l.etaB);
+        float sq = dwo + eta * dwi;
+        float factor = 1 / eta;
+        float v = fabsf((((((((l.dist.D(wh) * l.dist.G(wo, wi)) * eta) * eta) * fabsf(dwi)) * fabsf(dwo)) * factor) * factor) / (((cosI * cosO) * sq) * sq));
+        return f3((Fm * l.R.x) * v, (Fm * l.R.y) * v, (Fm * l.R.z) * v);
+    }
     return f3(0.f, 0.f, 0.f);
+}
+
+// BxDF::Pdf for a direction another lobe sampled: reflection.cpp:107-109 (Lambert), 262-266 / 296-300 (microfacet reflection),
+// 346-355 (microfacet transmission).
+__device__ __forceinline__ float lobe_pdf(const Lobe &l, F3 wo, F3 wi) {
+    if (l.kind == 1) return same_hemisphere(wo, wi) ? fabsf(wi.z) * RT_INV_PI : 0.f;
+    if (l.kind == 4 || l.kind == 5 || l.kind == 6) {
+        if (!same_hemisphere(wo, wi)) return 0.f;
+        F3 wh = normalize3(wo + wi);
+        return l.dist.Pdf(wo, wh) / (4 * dot3(wo, wh));
+    }
+    if (l.kind == 7) {
+        if (same_hemisphere(wo, wi)) return 0.f;
+        float eta = wo.z > 0 ? (l.etaB / l.etaA) : (l.etaA / l.etaB);
+        F3 wh = normalize3(wo + eta * wi);
+        float dwo = dot3(wo, wh), dwi = dot3(wi, wh);
+        if (dwo * dwi > 0) return 0.f;
+        float sq = dwo + eta * dwi;
+        float dwh_dwi = fabsf(((eta * eta) * dwi) / (sq * sq));
+        return l.dist.Pdf(wo, wh) * dwh_dwi;
+    }
+    return 0.f;
 }
 
 // BxDF::Sample_f in the local frame: reflection.cpp:99-105 (Lambert), 62-68 (mirror, FresnelNoOp),
@@ -673,19 +712,23 @@ __device__ __forceinline__ F3 lobe_sample(const Lobe &l, F3 wo, float u0, float 
         pdf = l.dist.Pdf(wo, wh) / (4 * dwh);
         return lobe_f(l, wo, wi);
     }
+    if (l.kind == 7) {                                                   // MicrofacetTransmission::Sample_f, reflection.cpp:334-344
+        if (wo.z == 0) return f3(0.f, 0.f, 0.f);
+        F3 wh = l.dist.Sample_wh(wo, u0, u1);
+        float cosThetaI = dot3(wh, wo);
+        if (cosThetaI < 0) return f3(0.f, 0.f, 0.f);
+        float eta = wo.z > 0 ? (l.etaA / l.etaB) : (l.etaB / l.etaA);
+        float sin2ThetaI = fmaxf(0.f, 1 - cosThetaI * cosThetaI);        // Refract about wh, reflection.h:52-61
+        float sin2ThetaT = eta * eta * sin2ThetaI;
+        if (sin2ThetaT >= 1) return f3(0.f, 0.f, 0.f);
+        float cosThetaT = sqrtf(1 - sin2ThetaT);
+        wi = eta * (-wo) + (eta * cosThetaI - cosThetaT) * wh;
+        pdf = lobe_pdf(l, wo, wi);
+        return lobe_f(l, wo, wi);
+    }
     return f3(0.f, 0.f, 0.f);
 }
 
-// BxDF::Pdf for a direction another lobe sampled: reflection.cpp:107-109 (Lambert), 262-266 / 296-300 (microfacet lobes).
-__device__ __forceinline__ float lobe_pdf(const Lobe &l, F3 wo, F3 wi) {
-    if (l.kind == 1) return same_hemisphere(wo, wi) ? fabsf(wi.z) * RT_INV_PI : 0.f;
-    if (l.kind == 4 || l.kind == 5 || l.kind == 6) {
-        if (!same_hemisphere(wo, wi)) return 0.f;
-        F3 wh = normalize3(wo + wi);
-        return l.dist.Pdf(wo, wh) / (4 * dot3(wo, wh));
-    }
-    return 0.f;
-}
 
 template <int MAT>
 __device__ __forceinline__ bool material_needs_uv(const DevScene &sc, const DevMaterial &m) {
@@ -698,7 +741,7 @@ __device__ __forceinline__ bool material_needs_uv(const DevScene &sc, const DevM
 // Material::ComputeScatteringFunctions, material.cpp:5-82.
 template <int MAT>
 __device__ __forceinline__ void build_lobe(const DevScene &sc, const DevMaterial &m, float u, float v, Lobe &l) {
-    l.kind = 0; l.R = l.eta = l.k = f3(0.f, 0.f, 0.f); l.etaB = 1.f; l.metallic = 0.f; l.dist.ax = l.dist.ay = 1.f;
+    l.kind = 0; l.R = l.eta = l.k = f3(0.f, 0.f, 0.f); l.etaA = l.etaB = 1.f; l.metallic = 0.f; l.dist.ax = l.dist.ay = 1.f;
     if (MAT == RT_MAT_MATTE) { l.kind = 1; l.R = clamp0(eval_texture(sc.textures[m.tex[0]], u, v)); }
     else if (MAT == RT_MAT_MIRROR) {
         F3 R = clamp0(eval_texture(sc.textures[m.tex[0]], u, v));
@@ -716,6 +759,14 @@ __device__ __forceinline__ void build_lobe(const DevScene &sc, const DevMaterial
     } else if (MAT == RT_MAT_PLASTIC) {          // first lobe only: Lambert(kd) if kd is not black; the glossy lobe is build_plastic_gloss
         F3 kd = clamp0(eval_texture(sc.textures[m.tex[0]], u, v));
         if (!black3(kd)) { l.kind = 1; l.R = kd; }
+    } else if (MAT == RT_MAT_ROUGHGLASS) {       // first lobe only: the reflection, if Kr is not black; the transmission is build_second_lobe
+        F3 R = clamp0(eval_texture(sc.textures[m.tex[0]], u, v));
+        if (!black3(R)) {
+            float rough = eval_texture(sc.textures[m.tex[3]], u, v).x;
+            if (m.remap) rough = roughness_to_alpha(rough);
+            l.kind = 6; l.R = R; l.etaA = 1.f; l.etaB = eval_texture(sc.textures[m.tex[2]], u, v).x;
+            l.dist.ax = fmaxf(0.001f, rough); l.dist.ay = fmaxf(0.001f, rough);
+        }
     } else if (MAT == RT_MAT_METALROUGH) {
         F3 c = clamp0(eval_texture(sc.textures[m.tex[0]], u, v));
         if (m.tex[1] < 0) { l.kind = 1; l.R = c; }
@@ -730,13 +781,41 @@ __device__ __forceinline__ void build_lobe(const DevScene &sc, const DevMaterial
 
 // PlasticMaterial's MicrofacetReflection(ks, TrowbridgeReitz(rough, rough), FresnelDielectric(1.5, 1)), material.cpp:41-48.
 __device__ __forceinline__ void build_plastic_gloss(const DevScene &sc, const DevMaterial &m, float u, float v, Lobe &l) {
-    l.kind = 0; l.R = l.eta = l.k = f3(0.f, 0.f, 0.f); l.etaB = 1.f; l.metallic = 0.f; l.dist.ax = l.dist.ay = 1.f;
+    l.kind = 0; l.R = l.eta = l.k = f3(0.f, 0.f, 0.f); l.etaA = l.etaB = 1.f; l.metallic = 0.f; l.dist.ax = l.dist.ay = 1.f;
     F3 ks = clamp0(eval_texture(sc.textures[m.tex[1]], u, v));
     if (black3(ks)) return;
     float rough = eval_texture(sc.textures[m.tex[2]], u, v).x;
     if (m.remap) rough = roughness_to_alpha(rough);
-    l.kind = 6; l.R = ks;
+    l.kind = 6; l.R = ks; l.etaA = 1.5f; l.etaB = 1.f;
     l.dist.ax = fmaxf(0.001f, rough); l.dist.ay = fmaxf(0.001f, rough);
+}
+
+// The rough dielectric's MicrofacetTransmission(Kt, TrowbridgeReitz(rough, rough), 1, index, Radiance): the second lobe after the reflection.
+__device__ __forceinline__ void build_roughglass_trans(const DevScene &sc, const DevMaterial &m, float u, float v, Lobe &l) {
+    l.kind = 0; l.R = l.eta = l.k = f3(0.f, 0.f, 0.f); l.etaA = l.etaB = 1.f; l.metallic = 0.f; l.dist.ax = l.dist.ay = 1.f;
+    F3 T = clamp0(eval_texture(sc.textures[m.tex[1]], u, v));
+    if (black3(T)) return;
+    float rough = eval_texture(sc.textures[m.tex[3]], u, v).x;
+    if (m.remap) rough = roughness_to_alpha(rough);
+    l.kind = 7; l.R = T; l.etaB = eval_texture(sc.textures[m.tex[2]], u, v).x;
+    l.dist.ax = fmaxf(0.001f, rough); l.dist.ay = fmaxf(0.001f, rough);
+}
+
+// BSDF::f over the non-specular lobes (reflection.cpp:140-152): the geometric side test picks the reflection or the transmission lobes.
+// Only the rough dielectric has a transmission lobe here, so every other material keeps the plain 'if (reflect)' form.
+template <int MAT>
+__device__ __forceinline__ F3 bsdf_f(const Lobe &lobe, const Lobe &lobe2, const int nlobes, bool reflect, F3 wol, F3 wil) {
+    F3 f = f3(0.f, 0.f, 0.f);
+    if (MAT != RT_MAT_ROUGHGLASS) {
+        if (reflect) {
+            f = lobe_f(lobe, wol, wil);
+            if (nlobes == 2) f = f + lobe_f(lobe2, wol, wil);
+        }
+    } else {
+        if (reflect != lobe_transmits(lobe.kind)) f = lobe_f(lobe, wol, wil);
+        if (nlobes == 2 && reflect != lobe_transmits(lobe2.kind)) f = f + lobe_f(lobe2, wol, wil);
+    }
+    return f;
 }
 
 // Small scenes: every table the shading code follows a slot through (slot -> material -> textures, slot -> vertices /
@@ -791,11 +870,7 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
                 if (nlobes == 2) { pdf += lobe_pdf(other, wol, wil); pdf /= nlobes; }      // reflection.cpp:199-204
                 if (!lobe_is_specular(chosen.kind)) {
                     bool reflect = dot3(wiW, sp.n) * dot3(woW, sp.n) > 0;
-                    f = f3(0.f, 0.f, 0.f);
-                    if (reflect) {
-                        f = lobe_f(lobe, wol, wil);
-                        if (nlobes == 2) f = f + lobe_f(lobe2, wol, wil);
-                    }
+                    f = bsdf_f<MAT>(lobe, lobe2, nlobes, reflect, wol, wil);
                 }
                 if (!black3(f) && pdf != 0.f) {
                     float ad = fabsf(dot3(wiW, sp.n));
@@ -823,14 +898,18 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
         build_lobe<RT_MAT_MIRROR>(sc, m, sp.u, sp.v, lm);
         if (lm.kind != 0) sample_bsdf(lm, none, 1);
     } else {
-        Lobe lobe, lobe2;       // lobe2: only PlasticMaterial has a second lobe (BSDF::Add order: Lambert, then microfacet)
+        Lobe lobe, lobe2;       // lobe2: PlasticMaterial (BSDF::Add order: Lambert, then microfacet) and the rough dielectric (reflection, then transmission)
         build_lobe<MAT>(sc, m, sp.u, sp.v, lobe);
         lobe2.kind = 0;
         if (MAT == RT_MAT_PLASTIC) {
             build_plastic_gloss(sc, m, sp.u, sp.v, lobe2);
             if (lobe.kind == 0) { lobe = lobe2; lobe2.kind = 0; }
         }
-        const int nlobes = (MAT == RT_MAT_PLASTIC && lobe2.kind != 0) ? 2 : 1;
+        if (MAT == RT_MAT_ROUGHGLASS) {
+            build_roughglass_trans(sc, m, sp.u, sp.v, lobe2);
+            if (lobe.kind == 0) { lobe = lobe2; lobe2.kind = 0; }
+        }
+        const int nlobes = ((MAT == RT_MAT_PLASTIC || MAT == RT_MAT_ROUGHGLASS) && lobe2.kind != 0) ? 2 : 1;
         // ---- next-event estimation: UniformSampleOneLight + EstimateDirect, integrator.cpp:53-102,259-264
         if (lobe.kind != 0 && !lobe_is_specular(lobe.kind) && sc.n_lights > 0) {
             int nL = sc.n_lights;
@@ -849,10 +928,7 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
                     F3 f = f3(0.f, 0.f, 0.f);
                     if (wol.z != 0) {
                         bool reflect = dot3(wi, sp.n) * dot3(sp.wo, sp.n) > 0;
-                        if (reflect) {
-                            f = lobe_f(lobe, wol, wil);
-                            if (nlobes == 2) f = f + lobe_f(lobe2, wol, wil);
-                        }
+                        f = bsdf_f<MAT>(lobe, lobe2, nlobes, reflect, wol, wil);
                     }
                     float ad = fabsf(dot3(wi, sp.n));
                     f = f3(f.x * ad, f.y * ad, f.z * ad);
@@ -895,10 +971,7 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
                 F3 f = f3(0.f, 0.f, 0.f);
                 if (wol.z != 0) {
                     bool reflect = dot3(wi, sp.n) * dot3(sp.wo, sp.n) > 0;
-                    if (reflect) {
-                        f = lobe_f(lobe, wol, wil);
-                        if (nlobes == 2) f = f + lobe_f(lobe2, wol, wil);
-                    }
+                    f = bsdf_f<MAT>(lobe, lobe2, nlobes, reflect, wol, wil);
                 }
                 float ad = fabsf(dot3(wi, sp.n));
                 f = f3(f.x * ad, f.y * ad, f.z * ad);
@@ -1135,6 +1208,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_finish(DevScene sc_in, RenderParam
                     case RT_MAT_GLASS: shade_path<RT_MAT_GLASS>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
                     case RT_MAT_METAL: shade_path<RT_MAT_METAL>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
                     case RT_MAT_PLASTIC: shade_path<RT_MAT_PLASTIC>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
+                    case RT_MAT_ROUGHGLASS: shade_path<RT_MAT_ROUGHGLASS>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
                     default: shade_path<RT_MAT_METALROUGH>(sc, rp, o, d, T, id, state, slot, L.tmax, L.b0, L.b1, L.b2, out); break;
                 }
                 if (out.has_shadow) {                               // bvh.cpp:284-320; tMax = 1 - ShadowEpsilon (interaction.h:27-32)
@@ -1562,7 +1636,7 @@ struct rt_scene {
     DevScene dev;
     std::vector<rt_bvh_node> nodes; std::vector<int32_t> order;
     int n_prims = 0;
-    bool classes[RT_NUM_CLASSES] = {false, false, false, false, false, false};
+    bool classes[RT_NUM_CLASSES] = {};
     DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_envs, d_spill, d_pairs, d_quads;
     int interior_depth = 0;
     std::vector<float> survival;     // fraction of a pass's paths still alive at each bounce, from the last pass that ran every bounce (k_finish)
@@ -1649,7 +1723,7 @@ static std::string check_desc(const rt_scene_desc *d) {
     for (int i = 0; i < d->n_materials; ++i) {
         const rt_material &m = d->materials[i];
         if (m.kind < 0 || m.kind >= RT_NUM_CLASSES) return "unknown material kind";
-        int need = m.kind == RT_MAT_MATTE || m.kind == RT_MAT_MIRROR ? 1 : m.kind == RT_MAT_GLASS || m.kind == RT_MAT_PLASTIC ? 3 : m.kind == RT_MAT_METAL ? 4 : 1;
+        int need = m.kind == RT_MAT_MATTE || m.kind == RT_MAT_MIRROR ? 1 : m.kind == RT_MAT_GLASS || m.kind == RT_MAT_PLASTIC ? 3 : (m.kind == RT_MAT_METAL || m.kind == RT_MAT_ROUGHGLASS) ? 4 : 1;
         for (int k = 0; k < 4; ++k)
             if (m.tex[k] >= d->n_textures || m.tex[k] < -1 || (k < need && m.tex[k] < 0)) return "material texture slot out of range";
     }
@@ -2183,7 +2257,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     const int ncu = std::max(1, ctx->n_cu);
     const bool small_tree = this_->dev.n_nodes <= 4096;
     // (the metal and plastic shading kernels need more than the 96 registers that five waves per SIMD leave each lane)
-    const bool five_fit = !this_->classes[RT_MAT_METAL] && !this_->classes[RT_MAT_PLASTIC];
+    const bool five_fit = !this_->classes[RT_MAT_METAL] && !this_->classes[RT_MAT_PLASTIC] && !this_->classes[RT_MAT_ROUGHGLASS];
     int nseg = env_int("RT_AMD_FRAME_BLOCKS_PER_CU", (small_tree || five_fit) ? 5 : 4) * ncu;
     nseg = std::max(RT_BLOCK, std::min(RT_SEG_BLOCKS, nseg / RT_BLOCK * RT_BLOCK));
     // segment capacity: a block's share of the pass, plus room for the rounding of every class kernel's share
@@ -2308,6 +2382,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                 if (this_->classes[RT_MAT_METAL]) launch_shade<RT_MAT_METAL>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
                 if (this_->classes[RT_MAT_PLASTIC]) launch_shade<RT_MAT_PLASTIC>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
                 if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
+                if (this_->classes[RT_MAT_ROUGHGLASS]) launch_shade<RT_MAT_ROUGHGLASS>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
                 tm.mark(RT_TIME_SHADE);
                 if (this_->dev.n_lights > 0 && !fuse_shadow) {
                     if (frame_old || b < round_bounces) {

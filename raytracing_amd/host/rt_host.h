@@ -323,6 +323,18 @@ public:
 private:
     SpectrumTex eta, k; FloatTex roughness, uRoughness, vRoughness; bool remapRoughness;
 };
+// Rough dielectric: MicrofacetReflection(Kr, TrowbridgeReitz(rough, rough), FresnelDielectric(1, index)) +
+// MicrofacetTransmission(Kt, TrowbridgeReitz(rough, rough), 1, index, Radiance).  The reference has both lobes
+// (include/core/reflection.cpp:241-266,311-355) but no material that assembles them; this one does, the way pbrt's glass does.
+class RoughGlassMaterial : public Material {
+public:
+    RoughGlassMaterial(const SpectrumTex &Kr, const SpectrumTex &Kt, const FloatTex &roughness, const FloatTex &index, bool remapRoughness)
+        : Kr(Kr), Kt(Kt), roughness(roughness), index(index), remapRoughness(remapRoughness) {}
+    int Kind() const override { return RT_MAT_ROUGHGLASS; }
+    void Slots(const TextureBase *s[4], int *remap) const override { s[0] = Kr.get(); s[1] = Kt.get(); s[2] = index.get(); s[3] = roughness.get(); *remap = remapRoughness; }
+private:
+    SpectrumTex Kr, Kt; FloatTex roughness, index; const bool remapRoughness;
+};
 class MetalRoughnessMaterial : public Material {
 public:
     MetalRoughnessMaterial(const SpectrumTex &base_color, const SpectrumTex &metalroughness)

@@ -76,7 +76,9 @@ void AddCeilingLight(BuiltScene &bs, std::vector<std::shared_ptr<Primitive>> &pr
 // plastic: the short cube gets a PlasticMaterial (not in the reference's scene; exercises the two-lobe BSDF of material.cpp:32-49)
 // env: an InfiniteAreaLight (include/core/infinite.h) joins the two ceiling triangles in scene.lights; the room's front is open, so
 // its light reaches the inside (no shipped scene constructs one)
-void BuildCornell(BuiltScene &bs, bool plastic = false, const std::string &envMap = "") {
+// roughGlass: the short cube is a rough dielectric (RoughGlassMaterial: the reference's MicrofacetTransmission lobe, which none of its
+// own materials uses, next to a dielectric-Fresnel MicrofacetReflection)
+void BuildCornell(BuiltScene &bs, bool plastic = false, const std::string &envMap = "", bool roughGlass = false) {
     std::vector<std::shared_ptr<Primitive>> prims; std::vector<std::shared_ptr<Light>> lights;
     AddCeilingLight(bs, prims, lights, Matte(Spectrum(1.0f, 1.0f, 1.0f)), 20.f);
     std::shared_ptr<Material> mirror = make_shared<MirrorMaterial>(Const(Spectrum(1.f)));
@@ -88,6 +90,7 @@ void BuildCornell(BuiltScene &bs, bool plastic = false, const std::string &envMa
     auto cube = BoxTriangles(bs, Translate(Vector3f(0.7f, 0.f, 2.8f)) * RotateY(18) * Transform(), 12, h, h, h);
     std::shared_ptr<Material> mcube = mwhite;
     if (plastic) mcube = make_shared<PlasticMaterial>(Const(Spectrum(.25f, .35f, .65f)), Const(Spectrum(.4f, .4f, .4f)), ConstF(0.15f), true);
+    if (roughGlass) mcube = make_shared<RoughGlassMaterial>(Const(Spectrum(.9f, .9f, .9f)), Const(Spectrum(.95f, .85f, .7f)), ConstF(0.25f), ConstF(1.5f), true);
     for (int i = 0; i < 12; ++i) prims.push_back(make_shared<GeometricPrimitive>(cube[i], mcube, nullptr));
     // the tall block: its "top" face sits at y = h while the sides reach 2h (RayTracing.cpp:166-167)
     auto block = BoxTriangles(bs, Translate(Vector3f(2.7f, 0.f, 1.0f)) * RotateY(-15) * Transform(), 12, h, h, h * 2);
@@ -279,6 +282,7 @@ rth_scene *rth_scene_build(const char *name, const char *assets_dir, int64_t par
         else if (nm == "spheres2") BuildSpheres(h->b, true, assets);
         else if (nm == "spheres3") BuildSpheres(h->b, true, assets, true);
         else if (nm == "cornell_metal") BuildCornellMetal(h->b);
+        else if (nm == "cornell_roughglass") BuildCornell(h->b, false, "", true);
         else if (nm == "cornell_env") BuildCornell(h->b, false, assets + "/env_48x20.hdr");
         else if (nm == "spheres_env") BuildSpheres(h->b, true, assets, false, true);
         else if (nm == "helmet") BuildHelmet(h->b, assets);

@@ -236,6 +236,10 @@ if __name__ == "__main__":
     # MetalMaterial (conductor Fresnel, anisotropic roughness, remap), a light with vertex normals, one with reverseOrientation, a two-sided one
     if not only or "cornell_metal" in only:
         golden_for_scene("cornell_metal", 2048, [(100, 100, 16, 16, [A, B])])
+    # MicrofacetTransmission (reflection.cpp:311-355), which no material of the reference adds to a BSDF: the driver's test material pairs it with
+    # a dielectric MicrofacetReflection on the short cube
+    if not only or "cornell_roughglass" in only:
+        golden_for_scene("cornell_roughglass", 2048, [(100, 100, 16, 16, [A, B])])
     # a 300 x 200 texture (resampled to powers of two by the reference itself) behind UVMapping2D(2, 3, 0.25, 0.5)
     if not only or "spheres3" in only:
         golden_for_scene("spheres3", 2048, [(96, 96, 8, 8, [A, B])])

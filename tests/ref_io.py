@@ -13,6 +13,7 @@ CAMERAS = {   # eye, look, up of the reference's scene functions (RayTracing.cpp
     "spheres2": ((13, 2, 3), (0, 0, 0), (0, 1, 0)),
     "spheres3": ((13, 2, 3), (0, 0, 0), (0, 1, 0)),
     "cornell_metal": ((2.5, 2.5, 11.8), (2.5, 2.5, 0.0), (0, 1, 0)),
+    "cornell_roughglass": ((2.5, 2.5, 11.8), (2.5, 2.5, 0.0), (0, 1, 0)),
     "cornell_env": ((2.5, 2.5, 11.8), (2.5, 2.5, 0.0), (0, 1, 0)),
     "spheres_env": ((13, 2, 3), (0, 0, 0), (0, 1, 0)),
     "helmet": ((3.5, 3.2, 1.5), (2.0, 2.3, 2.8), (0, 1, 0)),

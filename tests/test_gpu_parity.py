@@ -10,7 +10,7 @@ import pytest
 import raytracing_amd as ra
 
 pytestmark = pytest.mark.gpu
-SCENES = ["cornell", "cornell_plastic", "cornell_metal", "cornell_env", "sphere1", "spheres2", "spheres3", "spheres_env", "helmet"]
+SCENES = ["cornell", "cornell_plastic", "cornell_metal", "cornell_roughglass", "cornell_env", "sphere1", "spheres2", "spheres3", "spheres_env", "helmet"]
 
 
 def _rel_close(img, ref, tol):
@@ -194,7 +194,7 @@ def test_trace_edge_cases(device_scene):
     assert prim[0] == -1
 
 
-@pytest.mark.parametrize("name,w,sx", [("cornell", 96, 4), ("cornell_plastic", 96, 4), ("cornell_metal", 96, 4), ("cornell_env", 96, 4), ("sphere1", 96, 4),
+@pytest.mark.parametrize("name,w,sx", [("cornell", 96, 4), ("cornell_plastic", 96, 4), ("cornell_metal", 96, 4), ("cornell_roughglass", 96, 4), ("cornell_env", 96, 4), ("sphere1", 96, 4),
                                        ("spheres2", 96, 4), ("spheres3", 96, 4), ("spheres_env", 96, 4), ("helmet", 96, 4)])
 def test_render_matches_oracle_per_pixel(name, w, sx, device_scene, oracle_scene, host_scene):
     """Same sampler on both sides: identical ray counts (up to a handful of paths whose branch flips on a last-bit libm
@@ -207,11 +207,16 @@ def test_render_matches_oracle_per_pixel(name, w, sx, device_scene, oracle_scene
     assert abs(int(st.rays_closest) - int(cnt["closest"])) <= 1e-4 * cnt["closest"] + 4
     assert abs(int(st.rays_shadow) - int(cnt["shadow"])) <= 1e-4 * cnt["shadow"] + 4
     close = _rel_close(img, ref, 2e-3)
-    assert close.mean() > 0.995, close.mean()
-    assert np.all(np.abs(img.mean(axis=(0, 1)) / ref.mean(axis=(0, 1)) - 1) < 2e-3)
+    # Paths through the rough dielectric are ill-conditioned in the reference's own arithmetic (the visible-normal sampler's
+    # 'B * tmp - D' cancels for u near 0 and near G1; a path re-entering the cube after a diffuse bounce carries the last-bit
+    # difference between the device's and the host's sine and cosine into it): the oracle differs from ITSELF in 1.6 % of these
+    # pixels when the angle of its cosine-hemisphere sampler is scaled by 1 + 1e-7, and in none of cornell_plastic's or cornell_metal's.
+    floor = 0.985 if name == "cornell_roughglass" else 0.995
+    assert close.mean() > floor, close.mean()
+    assert np.all(np.abs(img.mean(axis=(0, 1)) / ref.mean(axis=(0, 1)) - 1) < (5e-3 if name == "cornell_roughglass" else 2e-3))
 
 
-@pytest.mark.parametrize("name,w,spp", [("cornell", 100, 256), ("cornell_plastic", 100, 256), ("cornell_metal", 100, 256), ("cornell_env", 100, 256), ("spheres2", 96, 64),
+@pytest.mark.parametrize("name,w,spp", [("cornell", 100, 256), ("cornell_plastic", 100, 256), ("cornell_metal", 100, 256), ("cornell_roughglass", 100, 256), ("cornell_env", 100, 256), ("spheres2", 96, 64),
                                         ("spheres3", 96, 64), ("spheres_env", 96, 400), ("helmet", 96, 64), ("sphere1", 64, 16)])
 def test_render_within_reference_noise_floor(name, w, spp, device_scene, host_scene, gold_dir):
     """Against images rendered by the reference's PathIntegrator::Li_re with its own sampler: per-channel mean within
@@ -304,7 +309,7 @@ def test_headline_frame_against_reference_and_shipped_image(device_scene, host_s
     assert np.all(np.abs(ratio - 1) < 0.03), ratio
 
 
-@pytest.mark.parametrize("name,w", [("cornell", 200), ("cornell_plastic", 120), ("cornell_metal", 120), ("cornell_env", 120), ("helmet", 160), ("spheres2", 160),
+@pytest.mark.parametrize("name,w", [("cornell", 200), ("cornell_plastic", 120), ("cornell_metal", 120), ("cornell_roughglass", 120), ("cornell_env", 120), ("helmet", 160), ("spheres2", 160),
                                     ("spheres_env", 120)])
 def test_frame_walks_give_identical_images(name, w, device_scene, host_scene, monkeypatch):
     """The frame kernels have three walks (round-based over pair/quad records, persistent lanes, round-based over plain

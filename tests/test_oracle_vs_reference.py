@@ -15,9 +15,11 @@ from raytracing_amd import capi
 # cornell_metal: MetalMaterial (conductor Fresnel; isotropic without remap and anisotropic with it), a light triangle with vertex
 # normals, one with reverseOrientation, a two-sided one.  spheres3: a 300 x 200 texture the reference resamples to powers of two
 # itself, looked up through a scaled and shifted UVMapping2D.
+# cornell_roughglass: MicrofacetTransmission, a lobe the reference defines but none of its materials uses (the reference driver's test
+# material puts it into a BSDF next to a dielectric MicrofacetReflection).
 # cornell_env / spheres_env: an InfiniteAreaLight (infinite.cpp, which the reference's project file leaves out of its build) over a
 # synthetic 48 x 20 .hdr map, next to the area lights and as the only light.
-SCENES = ["cornell", "cornell_plastic", "cornell_metal", "cornell_env", "sphere1", "spheres2", "spheres3", "spheres_env", "helmet"]
+SCENES = ["cornell", "cornell_plastic", "cornell_metal", "cornell_roughglass", "cornell_env", "sphere1", "spheres2", "spheres3", "spheres_env", "helmet"]
 
 
 @pytest.mark.parametrize("name", SCENES)
@@ -124,6 +126,11 @@ def test_new_scenes_reach_the_branches_they_were_built_for(host_scene, oracle_sc
     mats = [m for m in range(d.n_materials) if d.materials[m].tex[0] == odd[0]]
     hit = [p for p in g["out"][:, 0].astype(int) if p >= 0 and d.prim_material[p] in mats]
     assert len(hit) >= 3, "no probe lands on the sphere with the 300 x 200 texture"
+    g = np.load(os.path.join(gold_dir, "ref_probe_cornell_roughglass.npz"))
+    sampled = g["out"][:, 25].astype(int)
+    assert (sampled == 10).sum() >= 10 and (sampled == 9).sum() >= 5          # MicrofacetTransmission / MicrofacetReflection sampled
+    trans = g["out"][sampled == 10]
+    assert (trans[:, 15:18].max(axis=1) > 0).sum() >= 3                       # ... and f() of the probe direction through the surface
 
 
 @pytest.mark.parametrize("name", ["cornell_env", "spheres_env"])
