@@ -172,12 +172,19 @@ typedef struct rt_render_opts {
     uint32_t seed_lo, seed_hi;     /* Philox key */
     int32_t  pool_paths;           /* path slots kept in flight; 0 = library default */
     int32_t  flags;                /* RT_RENDER_* */
+    float    rr_threshold;         /* PathIntegrator's rrThreshold (integrator.h:72, default 1); read only under RT_RENDER_LI */
 } rt_render_opts;
 
 enum {
     RT_RENDER_ACCUMULATE   = 1, /* add onto the existing contents of the sum buffer instead of clearing it */
-    RT_RENDER_TIME_KERNELS = 2  /* bracket every launch with HIP events and fill seconds_trace / _shade / _shadow / _other
+    RT_RENDER_TIME_KERNELS = 2, /* bracket every launch with HIP events and fill seconds_trace / _shade / _shadow / _other
                                    (costs a few percent: the events serialise the launches) */
+    RT_RENDER_LI           = 4, /* estimate with PathIntegrator::Li (integrator.cpp:175-229) instead of Li_re (:236-281), which is what
+                                   the reference's Render calls: emitted light is added wherever a camera or specular ray lands, without ending
+                                   the path; rays that leave the scene see the infinite lights; the light is picked through the uniform
+                                   Distribution1D; Russian roulette tests the whole path's throughput times etaScale against rr_threshold */
+    RT_RENDER_ALL_LIGHTS   = 8  /* direct lighting by UniformSampleAllLights (integrator.cpp:26-51, one sample per light) instead of
+                                   UniformSampleOneLight; costs one shading and one shadow launch per light and bounce */
 };
 
 typedef struct rt_render_stats {

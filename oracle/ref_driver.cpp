@@ -82,6 +82,77 @@ private:
     std::shared_ptr<Texture<Spectrum>> Kr, Kt; std::shared_ptr<Texture<Float>> index, rough; bool remap;
 };
 
+// The reference defines UniformSampleAllLights (integrator.cpp:26-51) but no integrator of it calls the function.  These two
+// estimators are the driver's: the control flow of PathIntegrator::Li_re / Li around the reference's own UniformSampleAllLights,
+// BSDF, light and scene code, so that the function can be exercised inside whole paths.
+struct AllLightsEstimator {
+    int maxDepth; Float rrThreshold; std::vector<int> one;
+    AllLightsEstimator(int maxDepth, Float rr, const Scene &scene) : maxDepth(maxDepth), rrThreshold(rr), one(scene.lights.size(), 1) {}
+    // recursive form, emission ends the path (the shape of Li_re, integrator.cpp:236-281)
+    Spectrum Recursive(const Ray &ray, const Scene &scene, Sampler &sampler, int depth, bool afterSpecular) const {
+        Spectrum L(0.f);
+        SurfaceInteraction isect;
+        bool hit = scene.Intersect(ray, &isect);
+        if (depth == 0 || afterSpecular || scene.lights.size() == 0) {
+            if (hit) { L += isect.Le(-ray.d); if (!L.IsBlack()) return L; }
+            else if (scene.lights.size() == 0) {
+                Vector3f u = Normalize(ray.d);
+                auto t = 0.5 * (u[1] + 1.0);
+                L += (1.0 - t) * Spectrum(1.0, 1.0, 1.0) + t * Spectrum(0.5, 0.7, 1.0);
+            }
+        }
+        if (!hit || depth >= maxDepth) return L;
+        isect.ComputeScatteringFunctions(ray, true);
+        if (isect.bsdf->NumComponents(BxDFType(BSDF_ALL & ~BSDF_SPECULAR)) > 0) L += UniformSampleAllLights(isect, scene, sampler, one, false);
+        Vector3f wo = -ray.d, wi; Float pdf; BxDFType flags;
+        Spectrum f = isect.bsdf->Sample_f(wo, &wi, sampler.Get2D(), &pdf, BSDF_ALL, &flags);
+        if (f.IsBlack() || pdf == 0.f) return L;
+        Spectrum beta = Spectrum(1.f) * (f * AbsDot(wi, isect.shading.n) / pdf);
+        Ray next = isect.SpawnRay(wi);
+        if (depth > 3) {
+            Float q = std::max((Float).05, 1 - beta.MaxComponentValue());
+            if (sampler.Get1D() < q) return L;
+            beta /= 1 - q;
+        }
+        return L + beta * Recursive(next, scene, sampler, depth + 1, (flags & BSDF_SPECULAR) != 0);
+    }
+    // iterative form with path throughput (the shape of Li, integrator.cpp:175-229)
+    Spectrum Iterative(const Ray &r, const Scene &scene, Sampler &sampler) const {
+        Spectrum L(0.f), beta(1.f);
+        Ray ray(r);
+        bool afterSpecular = false;
+        Float etaScale = 1;
+        for (int bounces = 0;; ++bounces) {
+            SurfaceInteraction isect;
+            bool hit = scene.Intersect(ray, &isect);
+            if (bounces == 0 || afterSpecular) {
+                if (hit) L += beta * isect.Le(-ray.d);
+                else for (const auto &light : scene.infiniteLights) L += beta * light->Le(ray);
+            }
+            if (!hit || bounces >= maxDepth) break;
+            isect.ComputeScatteringFunctions(ray, true);
+            if (isect.bsdf->NumComponents(BxDFType(BSDF_ALL & ~BSDF_SPECULAR)) > 0) L += beta * UniformSampleAllLights(isect, scene, sampler, one, false);
+            Vector3f wo = -ray.d, wi; Float pdf; BxDFType flags;
+            Spectrum f = isect.bsdf->Sample_f(wo, &wi, sampler.Get2D(), &pdf, BSDF_ALL, &flags);
+            if (f.IsBlack() || pdf == 0.f) break;
+            beta *= f * AbsDot(wi, isect.shading.n) / pdf;
+            afterSpecular = (flags & BSDF_SPECULAR) != 0;
+            if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+                Float eta = isect.bsdf->eta;
+                etaScale *= (Dot(wo, isect.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+            }
+            ray = isect.SpawnRay(wi);
+            Spectrum rrBeta = beta * etaScale;
+            if (rrBeta.MaxComponentValue() < rrThreshold && bounces > 3) {
+                Float q = std::max((Float).05, 1 - rrBeta.MaxComponentValue());
+                if (sampler.Get1D() < q) break;
+                beta /= 1 - q;
+            }
+        }
+        return L;
+    }
+};
+
 // ------------------------------------------------------------- scene dump --
 struct Reader {
     std::vector<uint8_t> buf; size_t p = 0;
@@ -321,14 +392,20 @@ int main(int argc, char **argv) {
         WriteAll(argv[4], out.data(), out.size() * 4);
         return 0;
     }
-    if (cmd == "render") {       // render scene.bin cam.bin sx sy max_depth seed_offset nproc out.f32  (sum of Li per pixel, W*H*3)
+    if (cmd == "render") {       // render scene.bin cam.bin sx sy max_depth seed_offset nproc out.f32 [estimator [rrThreshold]]  (sum of Li per pixel, W*H*3)
+                                 // estimator: 0 = PathIntegrator::Li_re (what the reference's Render calls), 1 = PathIntegrator::Li,
+                                 // 2 / 3 = the driver's AllLightsEstimator in its recursive / iterative form
         RefScene rs; LoadScene(argv[2], rs);
         Reader cr(argv[3]); CamSpec c = cr.get<CamSpec>();
         int sx = atoi(argv[4]), sy = atoi(argv[5]), maxDepth = atoi(argv[6]); long long seedOff = atoll(argv[7]); int nproc = std::max(1, atoi(argv[8]));
         auto cam = MakeCamera(c);
         std::shared_ptr<Sampler> ss = std::make_shared<StratifiedSampler>(sx, sy, true, 1);
         Bounds2i pixelBounds;
-        PathIntegrator integ(maxDepth, cam, ss, pixelBounds, 1.f);
+        const int estimator = argc > 10 ? atoi(argv[10]) : 0;
+        const Float rrThreshold = argc > 11 ? (Float)atof(argv[11]) : 1.f;
+        PathIntegrator integ(maxDepth, cam, ss, pixelBounds, rrThreshold);
+        integ.Preprocess(*rs.scene, *ss);
+        AllLightsEstimator all(maxDepth, rrThreshold, *rs.scene);
         int W = c.W, H = c.H;
         size_t bytes = (size_t)W * H * 3 * sizeof(float);
         float *img = (float *)mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
@@ -346,7 +423,10 @@ int main(int argc, char **argv) {
                             Ray r; CameraSample cs = ps->GetCameraSample(pixel);
                             cam->GenerateRay(cs, &r);
                             perfectspecular = false;
-                            col += integ.Li_re(r, *rs.scene, *ps, 0);
+                            if (estimator == 0) col += integ.Li_re(r, *rs.scene, *ps, 0);
+                            else if (estimator == 1) col += integ.Li(r, *rs.scene, *ps, 0);
+                            else if (estimator == 2) col += all.Recursive(r, *rs.scene, *ps, 0, false);
+                            else col += all.Iterative(r, *rs.scene, *ps);
                         } while (ps->StartNextSample());
                         float *px = img + 3 * ((size_t)j * W + i);
                         px[0] = col[0]; px[1] = col[1]; px[2] = col[2];

@@ -41,6 +41,7 @@ namespace {
 
 const Float Pi = 3.14159265358979323846;
 const Float InvPi = 0.31830988618379067154;
+const Float Inv2Pi = 0.15915494309189533577;
 const Float PiOver2 = 1.57079632679489661923;
 const Float PiOver4 = 0.78539816339744830961;
 const Float ShadowEpsilon = 0.0001f;
@@ -140,6 +141,7 @@ struct Scene {
     std::vector<rt_bvh_node> nodes; std::vector<int32_t> order;
     int n_prims = 0;
     std::vector<rt_env_light> envs; std::vector<std::vector<float>> env_store;    // infinite lights and the tables they point at
+    std::vector<float> light_cdf; float light_func_int = 0;     // Distribution1D of UniformLightDistribution (see LightDistrib)
 };
 
 struct Bounds { V3 pMin, pMax; };
@@ -1010,6 +1012,8 @@ struct Sampler {
     virtual void LightDims(Float *pick, Float *ul0, Float *ul1) { *pick = Get1D(); Get2D(ul0, ul1); Float a, b; Get2D(&a, &b); }
     virtual void BsdfDims(Float *u0, Float *u1) { Get2D(u0, u1); }
     virtual Float RRDim() { return Get1D(); }
+    // UniformSampleAllLights with no sample arrays requested (integrator.cpp:35-39): uLight, then uScattering (which EstimateDirect never reads)
+    virtual void AllLightDims(int light, Float *ul0, Float *ul1) { Get2D(ul0, ul1); Float a, b; Get2D(&a, &b); }
 };
 
 struct RefSampler : Sampler {
@@ -1048,6 +1052,11 @@ struct PhiloxSampler : Sampler {
     void LightDims(Float *pick, Float *ul0, Float *ul1) override { need0(); *pick = U32ToFloat(blk0[0]); *ul0 = U32ToFloat(blk0[1]); *ul1 = U32ToFloat(blk0[2]); }
     void BsdfDims(Float *u0, Float *u1) override { need1(); *u0 = U32ToFloat(blk1[0]); *u1 = U32ToFloat(blk1[1]); }
     Float RRDim() override { need0(); return U32ToFloat(blk0[3]); }
+    // block 2 + j = {uLight.x, uLight.y, -, -} of light j when every light is sampled
+    void AllLightDims(int light, Float *ul0, Float *ul1) override {
+        uint32_t c[4] = {pixel, sample, (uint32_t)depth, 2u + (uint32_t)light}; Philox4x32(c, k0, k1);
+        *ul0 = U32ToFloat(c[0]); *ul1 = U32ToFloat(c[1]);
+    }
     // film sample: counter (pixel, sample, 0xFFFFFFFF, 0); stratum = Kensler permutation of the sample index
     void Film(int nx, int ny, Float *fx, Float *fy) {
         uint32_t c[4] = {pixel, sample, 0xFFFFFFFFu, 0}; Philox4x32(c, k0, k1);
@@ -1088,6 +1097,14 @@ inline Float SampleContinuous1D(const float *func, const float *cdf, int n, Floa
     if (pdf) *pdf = (funcInt > 0) ? func[offset] / funcInt : 0;
     return (offset + du) / n;
 }
+// MIPMap::Lookup(st) for a zero filter width = triangle(0, st) with the Repeat wrap (mipmap.h:173-200)
+RGB EnvLookup(const rt_env_light &e, Float u, Float v) {
+    Float s = u * e.width - 0.5f, t = v * e.height - 0.5f;
+    int s0 = (int)std::floor(s), t0 = (int)std::floor(t);
+    Float ds = s - s0, dt = t - t0;
+    auto texel = [&](int a, int b) { const float *px = e.texels + 3 * ((size_t)ModI(b, e.height) * e.width + ModI(a, e.width)); return rgb(px[0], px[1], px[2]); };
+    return (1 - ds) * (1 - dt) * texel(s0, t0) + (1 - ds) * dt * texel(s0, t0 + 1) + ds * (1 - dt) * texel(s0 + 1, t0) + ds * dt * texel(s0 + 1, t0 + 1);
+}
 // InfiniteAreaLight::Sample_Li (infinite.cpp:83-106) with Distribution2D::SampleContinuous (sampling.h:72-79) and
 // MIPMap::Lookup(st) = triangle(0, st) for a zero filter width (mipmap.h:173-200).  Returns Li; *p1 = the far end of the
 // visibility segment.
@@ -1104,23 +1121,21 @@ RGB EnvSampleLi(const rt_env_light &e, V3 refP, Float u0, Float u1, V3 *wi, Floa
     *pdf = mapPdf / (2 * Pi * Pi * sinTheta);
     if (sinTheta == 0) *pdf = 0;
     *p1 = refP + *wi * (2 * e.world_radius);
-    // triangle(0, uv), Repeat wrap
-    Float s = d0 * e.width - 0.5f, t = d1 * e.height - 0.5f;
-    int s0 = (int)std::floor(s), t0 = (int)std::floor(t);
-    Float ds = s - s0, dt = t - t0;
-    auto texel = [&](int a, int b) { const float *px = e.texels + 3 * ((size_t)ModI(b, e.height) * e.width + ModI(a, e.width)); return rgb(px[0], px[1], px[2]); };
-    return (1 - ds) * (1 - dt) * texel(s0, t0) + (1 - ds) * dt * texel(s0, t0 + 1) + ds * (1 - dt) * texel(s0 + 1, t0) + ds * dt * texel(s0 + 1, t0 + 1);
+    return EnvLookup(e, d0, d1);
 }
 
-// integrator.cpp:53-102 + light.cpp:43-54 + shape.cpp:20-31 + triangle.cpp:229-248 + interaction.h:27-32
-RGB UniformSampleOneLight(const Scene &sc, const SurfaceInteraction &si, const BSDF &bsdf, Sampler &smp, PathCounters *pc) {
-    int nLights = (int)sc.lights.size();
-    if (nLights == 0) return rgb1(0.f);
-    Float pick, u0, u1;
-    smp.LightDims(&pick, &u0, &u1);
-    int lightNum = std::min((int)(pick * nLights), nLights - 1);
-    Float lightPdfSel = Float(1) / nLights;
-    const rt_light &light = sc.lights[lightNum];
+// InfiniteAreaLight::Le (infinite.cpp:77-81): the map looked up at the direction's spherical angles, zero filter width
+RGB EnvLe(const rt_env_light &e, V3 d) {
+    V3 w = Normalize(XfVector(e.world_to_light, d));
+    Float p = std::atan2(w.y, w.x);
+    Float phi = (p < 0) ? (p + 2 * Pi) : p;                       // SphericalPhi, geometry.h:939-942
+    Float theta = std::acos(Clamp(w.z, -1, 1));                   // SphericalTheta, geometry.h:935-937
+    return EnvLookup(e, phi * Inv2Pi, theta * InvPi);
+}
+
+// EstimateDirect without multiple importance sampling (integrator.cpp:74-102) for one light: light.cpp:43-54 + shape.cpp:20-31 +
+// triangle.cpp:229-248 + interaction.h:27-32 for a triangle light, infinite.cpp:83-106 for an infinite one
+RGB EstimateDirect(const Scene &sc, const SurfaceInteraction &si, const BSDF &bsdf, const rt_light &light, Float u0, Float u1, PathCounters *pc) {
     if (light.kind == RT_LIGHT_INFINITE) {      // EstimateDirect (integrator.cpp:74-102) around InfiniteAreaLight::Sample_Li
         V3 wi = mk(0, 0, 0), p1 = mk(0, 0, 0); Float lightPdf = 0;
         RGB Li = EnvSampleLi(sc.envs[light.env], si.p, u0, u1, &wi, &lightPdf, &p1);
@@ -1137,7 +1152,7 @@ RGB UniformSampleOneLight(const Scene &sc, const SurfaceInteraction &si, const B
                 if (!IsBlack(Li)) Ld = Ld + f * Li / lightPdf;
             }
         }
-        return Ld / lightPdfSel;
+        return Ld;
     }
     // Triangle::Sample
     size_t g = (size_t)sc.prim_geom[light.prim];
@@ -1178,11 +1193,56 @@ RGB UniformSampleOneLight(const Scene &sc, const SurfaceInteraction &si, const B
             if (!IsBlack(Li)) Ld = Ld + f * Li / pdf;
         }
     }
-    return Ld / lightPdfSel;
+    return Ld;
+}
+
+// Distribution1D of UniformLightDistribution (lightdistrib.cpp:12-15, sampling.h:16-27): func = 1 for every light
+inline void BuildLightCdf(int n, std::vector<float> &cdf, float &funcInt) {
+    cdf.assign(n + 1, 0.f);
+    for (int i = 1; i < n + 1; ++i) cdf[i] = cdf[i - 1] + Float(1) / n;
+    funcInt = cdf[n];
+    if (funcInt == 0) { for (int i = 1; i < n + 1; ++i) cdf[i] = Float(i) / Float(n); }
+    else for (int i = 1; i < n + 1; ++i) cdf[i] /= funcInt;
+}
+struct LightDistrib {
+    const std::vector<float> &cdf; Float funcInt; int n;
+    int SampleDiscrete(Float u, Float *pdf) const {     // sampling.h:40-48
+        int offset = FindInterval((int)cdf.size(), [&](int index) { return cdf[index] <= u; });
+        *pdf = (funcInt > 0) ? Float(1) / (funcInt * n) : 0;
+        return offset;
+    }
+};
+
+// integrator.cpp:53-72; distrib == nullptr is Li_re's call, a distribution is Li's
+RGB UniformSampleOneLight(const Scene &sc, const SurfaceInteraction &si, const BSDF &bsdf, Sampler &smp, PathCounters *pc, const LightDistrib *distrib = nullptr) {
+    int nLights = (int)sc.lights.size();
+    if (nLights == 0) return rgb1(0.f);
+    Float pick, u0, u1;
+    smp.LightDims(&pick, &u0, &u1);      // Get1D, Get2D (uLight), Get2D (uScattering): drawn before the early return below, which no light set here reaches
+    int lightNum; Float lightPdf;
+    if (distrib) {
+        lightNum = distrib->SampleDiscrete(pick, &lightPdf);
+        if (lightPdf == 0) return rgb1(0.f);
+    } else {
+        lightNum = std::min((int)(pick * nLights), nLights - 1);
+        lightPdf = Float(1) / nLights;
+    }
+    return EstimateDirect(sc, si, bsdf, sc.lights[lightNum], u0, u1, pc) / lightPdf;
+}
+
+// integrator.cpp:26-51 with one sample per light and no sample arrays requested from the sampler (the branch at :35-40)
+RGB UniformSampleAllLights(const Scene &sc, const SurfaceInteraction &si, const BSDF &bsdf, Sampler &smp, PathCounters *pc) {
+    RGB L = rgb1(0.f);
+    for (size_t j = 0; j < sc.lights.size(); ++j) {
+        Float u0, u1;
+        smp.AllLightDims((int)j, &u0, &u1);
+        L = L + EstimateDirect(sc, si, bsdf, sc.lights[j], u0, u1, pc);
+    }
+    return L;
 }
 
 // integrator.cpp:236-281.  `specular` is the per-path replacement of the global perfectspecular.
-RGB Li_re(const Scene &sc, const Ray &r, Sampler &smp, int depth, int maxDepth, bool *specular, PathCounters *pc) {
+RGB Li_re(const Scene &sc, const Ray &r, Sampler &smp, int depth, int maxDepth, bool *specular, PathCounters *pc, bool allLights = false) {
     RGB L = rgb1(0.f), beta = rgb1(1.f);
     Ray ray = r;
     Hit hit;
@@ -1206,7 +1266,7 @@ RGB Li_re(const Scene &sc, const Ray &r, Sampler &smp, int depth, int maxDepth, 
     ComputeScatteringFunctions(sc, si, &bsdf);
     smp.BeginBounce(depth);
     if (bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
-        RGB Ld = UniformSampleOneLight(sc, si, bsdf, smp, pc);
+        RGB Ld = allLights ? UniformSampleAllLights(sc, si, bsdf, smp, pc) : UniformSampleOneLight(sc, si, bsdf, smp, pc);
         L = L + Ld;
     }
     V3 wo = -ray.d, wi; Float pdf; int flags = 0;
@@ -1221,7 +1281,57 @@ RGB Li_re(const Scene &sc, const Ray &r, Sampler &smp, int depth, int maxDepth, 
         if (smp.RRDim() < q) return L;
         beta = beta / (1 - q);
     }
-    return L + beta * Li_re(sc, next, smp, depth + 1, maxDepth, specular, pc);
+    return L + beta * Li_re(sc, next, smp, depth + 1, maxDepth, specular, pc, allLights);
+}
+
+// PathIntegrator::Li, integrator.cpp:175-229 (every material here makes a BSDF, so the 'no bsdf' skip at :196-200 never runs)
+RGB Li(const Scene &sc, const Ray &r, Sampler &smp, int maxDepth, Float rrThreshold, bool allLights, PathCounters *pc) {
+    RGB L = rgb1(0.f), beta = rgb1(1.f);
+    Ray ray = r;
+    bool specularBounce = false;
+    Float etaScale = 1;
+    const LightDistrib distrib = {sc.light_cdf, sc.light_func_int, (int)sc.lights.size()};     // lightDistribution->Lookup(isect.p): the same for every point
+    for (int bounces = 0;; ++bounces) {
+        Hit hit;
+        if (pc) pc->closest++;
+        bool found = IntersectClosest(sc, ray, &hit, nullptr);
+        SurfaceInteraction si;
+        if (found) FillInteraction(sc, ray, hit, &si);
+        if (bounces == 0 || specularBounce) {
+            if (found) {
+                int li = sc.prim_light[hit.prim];
+                if (li >= 0) L = L + beta * LightL(sc.lights[li], si.n, -ray.d);
+            } else
+                for (const rt_light &l : sc.lights) if (l.kind == RT_LIGHT_INFINITE) L = L + beta * EnvLe(sc.envs[l.env], ray.d);
+        }
+        if (!found || bounces >= maxDepth) break;
+        BSDF bsdf;
+        ComputeScatteringFunctions(sc, si, &bsdf);
+        smp.BeginBounce(bounces);
+        if (bsdf.NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
+            RGB Ld = beta * (allLights ? UniformSampleAllLights(sc, si, bsdf, smp, pc) : UniformSampleOneLight(sc, si, bsdf, smp, pc, &distrib));
+            L = L + Ld;
+        }
+        V3 wo = -ray.d, wi; Float pdf; int flags = 0;
+        Float u0, u1; smp.BsdfDims(&u0, &u1);
+        RGB f = bsdf.Sample_f(wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
+        if (IsBlack(f) || pdf == 0.f) break;
+        beta = beta * (f * AbsDot(wi, si.n) / pdf);
+        specularBounce = (flags & BSDF_SPECULAR) != 0;
+        if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+            Float eta = bsdf.eta;
+            etaScale *= (Dot(wo, si.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+        }
+        Ray next = {OffsetRayOrigin(si.p, si.n, wi), wi, Infinity};
+        ray = next;
+        RGB rrBeta = beta * etaScale;
+        if (MaxComp(rrBeta) < rrThreshold && bounces > 3) {
+            Float q = std::max((Float).05, 1 - MaxComp(rrBeta));
+            if (smp.RRDim() < q) break;
+            beta = beta / (1 - q);
+        }
+    }
+    return L;
 }
 
 // camera.cpp:52-58
@@ -1267,7 +1377,7 @@ orc_scene *orc_scene_create(const rt_scene_desc *d) {
             s.texel_store[i].assign(d->textures[i].texels, d->textures[i].texels + n);
             s.textures[i].texels = s.texel_store[i].data();
         }
-    if (d->n_lights) s.lights.assign(d->lights, d->lights + d->n_lights);
+    if (d->n_lights) { s.lights.assign(d->lights, d->lights + d->n_lights); BuildLightCdf(d->n_lights, s.light_cdf, s.light_func_int); }
     for (int i = 0; i < d->n_env_lights; ++i) {
         rt_env_light e = d->env_lights[i];
         auto keep = [&](const float *p, size_t n) { s.env_store.emplace_back(p, p + n); return (const float *)s.env_store.back().data(); };
@@ -1337,6 +1447,7 @@ int orc_render(orc_scene *h, const rt_camera *cam, const rt_render_opts *opts, i
     int W = cam->width, H = cam->height, nx = opts->strata_x, ny = opts->strata_y;
     int64_t npix = (int64_t)W * H;
     if (threads < 1) threads = 1;
+    const bool use_li = (opts->flags & RT_RENDER_LI) != 0, all_lights = (opts->flags & RT_RENDER_ALL_LIGHTS) != 0;
     std::atomic<int64_t> next(0);
     std::vector<PathCounters> pcs(threads); std::vector<uint64_t> nsamp(threads, 0);
     auto work = [&](int tid) {
@@ -1359,7 +1470,8 @@ int orc_render(orc_scene *h, const rt_camera *cam, const rt_render_opts *opts, i
                             Float l0, l1; smp.Get2D(&l0, &l1);
                             Ray r = GenerateRay(*cam, (Float)i + fx, (Float)j + fy);
                             bool spec = false;
-                            col = col + Li_re(sc, r, smp, 0, opts->max_depth, &spec, &pc);
+                            col = col + (use_li ? Li(sc, r, smp, opts->max_depth, opts->rr_threshold, all_lights, &pc)
+                                                : Li_re(sc, r, smp, 0, opts->max_depth, &spec, &pc, all_lights));
                             ns++;
                         }
                     } while (smp.StartNextSample());
@@ -1370,7 +1482,8 @@ int orc_render(orc_scene *h, const rt_camera *cam, const rt_render_opts *opts, i
                         Float fx, fy; smp.Film(nx, ny, &fx, &fy);
                         Ray r = GenerateRay(*cam, (Float)i + fx, (Float)j + fy);
                         bool spec = false;
-                        col = col + Li_re(sc, r, smp, 0, opts->max_depth, &spec, &pc);
+                        col = col + (use_li ? Li(sc, r, smp, opts->max_depth, opts->rr_threshold, all_lights, &pc)
+                                            : Li_re(sc, r, smp, 0, opts->max_depth, &spec, &pc, all_lights));
                         ns++;
                     }
                 }

@@ -182,7 +182,7 @@ def write_ppm(path, sum_rgb, spp):
         raise RuntimeError("rt_write_ppm failed")
 
 
-def make_opts(sx, sy, begin=0, end=None, max_depth=50, seed=(0x243F6A88, 0x85A308D3), pool_paths=0, flags=0):
+def make_opts(sx, sy, begin=0, end=None, max_depth=50, seed=(0x243F6A88, 0x85A308D3), pool_paths=0, flags=0, rr_threshold=1.0):
     o = RenderOpts()
     o.strata_x, o.strata_y = sx, sy
     o.sample_begin, o.sample_end = begin, (sx * sy if end is None else end)
@@ -190,6 +190,7 @@ def make_opts(sx, sy, begin=0, end=None, max_depth=50, seed=(0x243F6A88, 0x85A30
     o.seed_lo, o.seed_hi = seed
     o.pool_paths = pool_paths
     o.flags = flags
+    o.rr_threshold = rr_threshold
     return o
 
 

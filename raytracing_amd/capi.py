@@ -70,7 +70,7 @@ class Camera(C.Structure):
 class RenderOpts(C.Structure):
     _fields_ = [("strata_x", C.c_int32), ("strata_y", C.c_int32), ("sample_begin", C.c_int32), ("sample_end", C.c_int32),
                 ("max_depth", C.c_int32), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
-                ("pool_paths", C.c_int32), ("flags", C.c_int32)]
+                ("pool_paths", C.c_int32), ("flags", C.c_int32), ("rr_threshold", C.c_float)]
 
 
 class RenderStats(C.Structure):
@@ -85,6 +85,8 @@ class TraceStats(C.Structure):
 
 RT_RENDER_ACCUMULATE = 1
 RT_RENDER_TIME_KERNELS = 2
+RT_RENDER_LI = 4
+RT_RENDER_ALL_LIGHTS = 8
 
 # Every symbol include/rt_amd.h declares.
 RT_AMD_SYMBOLS = [

@@ -15,6 +15,7 @@
 
 #define RT_PI 3.14159265358979323846f
 #define RT_INV_PI 0.31830988618379067154f
+#define RT_INV_2PI 0.15915494309189533577f
 #define RT_PI_OVER_2 1.57079632679489661923f
 #define RT_PI_OVER_4 0.78539816339744830961f
 #define RT_ONE_MINUS_EPS 0.99999994f
@@ -40,6 +41,7 @@ struct DevLight {
 // InfiniteAreaLight as Sample_Li reads it (infinite.cpp:83-106): radiance map level 0, Distribution2D tables, transform, scene radius.
 struct DevEnv {
     float l2w[12];                 // rows 0..2 of LightToWorld
+    float w2l[12];                 // rows 0..2 of WorldToLight
     int width, height, nu, nv;
     const float *texels, *func, *cdf, *func_int, *marginal_cdf;
     float marginal_int, world_radius;
@@ -66,6 +68,9 @@ struct DevScene {
     uint32_t pad;
     int n_materials, n_textures;
     const DevEnv *envs;       // infinite area lights
+    const float *light_cdf;   // n_lights + 1: cdf of the uniform Distribution1D over the lights (lightdistrib.cpp:12-15, sampling.h:16-27)
+    float light_func_int;     // its funcInt
+    int n_envs;
 };
 
 struct F3 { float x, y, z; };
@@ -354,6 +359,7 @@ __device__ __forceinline__ F3 eval_texture(const DevTexture &t, float u, float v
     return f3(A[0] * w00 + B[0] * w01 + Cc[0] * w10 + D[0] * w11, A[1] * w00 + B[1] * w01 + Cc[1] * w10 + D[1] * w11,
               A[2] * w00 + B[2] * w01 + Cc[2] * w10 + D[2] * w11);
 }
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ F3 clamp0(F3 a) { return f3(a.x < 0.f ? 0.f : a.x, a.y < 0.f ? 0.f : a.y, a.z < 0.f ? 0.f : a.z); }   // Spectrum::Clamp(0, inf)
 
 // Distribution1D::SampleContinuous (sampling.h:30-40) with FindInterval (pbrt.h:213-226) over func[0..n), cdf[0..n].
@@ -371,6 +377,19 @@ __device__ __forceinline__ float sample_continuous_1d(const float *func, const f
     pdf = (funcInt > 0) ? func[offset] / funcInt : 0.f;
     return (offset + du) / n;
 }
+// MIPMap::Lookup with a zero filter width: bilinear on level 0, Repeat wrap (mipmap.h:173-200)
+__device__ __forceinline__ F3 env_lookup(const DevEnv &e, float u, float v) {
+    float s = u * e.width - 0.5f, t = v * e.height - 0.5f;
+    float fs = floorf(s), ft = floorf(t);
+    int s0 = (int)fs, t0 = (int)ft;
+    float ds = s - s0, dt = t - t0;
+    int sa = mod_wrap(s0, e.width), sb = mod_wrap(s0 + 1, e.width), ta = mod_wrap(t0, e.height), tb = mod_wrap(t0 + 1, e.height);
+    const float *A = e.texels + 3 * ((size_t)ta * e.width + sa), *B = e.texels + 3 * ((size_t)tb * e.width + sa);
+    const float *Cc = e.texels + 3 * ((size_t)ta * e.width + sb), *D = e.texels + 3 * ((size_t)tb * e.width + sb);
+    float w00 = (1 - ds) * (1 - dt), w01 = (1 - ds) * dt, w10 = ds * (1 - dt), w11 = ds * dt;
+    return f3(A[0] * w00 + B[0] * w01 + Cc[0] * w10 + D[0] * w11, A[1] * w00 + B[1] * w01 + Cc[1] * w10 + D[1] * w11,
+              A[2] * w00 + B[2] * w01 + Cc[2] * w10 + D[2] * w11);
+}
 // InfiniteAreaLight::Sample_Li (infinite.cpp:83-106): Distribution2D::SampleContinuous (sampling.h:72-79), direction from the
 // (u, v) of the map, pdf with respect to solid angle, radiance = bilinear level-0 lookup (MIPMap::Lookup with zero width).
 __device__ __forceinline__ F3 env_sample_li(const DevEnv &e, float u0, float u1, F3 &wi, float &pdf) {
@@ -386,16 +405,15 @@ __device__ __forceinline__ F3 env_sample_li(const DevEnv &e, float u0, float u1,
     wi = xf_vector(e.l2w, f3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta));
     pdf = mapPdf / (2 * RT_PI * RT_PI * sinTheta);
     if (sinTheta == 0) pdf = 0.f;
-    float s = d0 * e.width - 0.5f, t = d1 * e.height - 0.5f;
-    float fs = floorf(s), ft = floorf(t);
-    int s0 = (int)fs, t0 = (int)ft;
-    float ds = s - s0, dt = t - t0;
-    int sa = mod_wrap(s0, e.width), sb = mod_wrap(s0 + 1, e.width), ta = mod_wrap(t0, e.height), tb = mod_wrap(t0 + 1, e.height);
-    const float *A = e.texels + 3 * ((size_t)ta * e.width + sa), *B = e.texels + 3 * ((size_t)tb * e.width + sa);
-    const float *Cc = e.texels + 3 * ((size_t)ta * e.width + sb), *D = e.texels + 3 * ((size_t)tb * e.width + sb);
-    float w00 = (1 - ds) * (1 - dt), w01 = (1 - ds) * dt, w10 = ds * (1 - dt), w11 = ds * dt;
-    return f3(A[0] * w00 + B[0] * w01 + Cc[0] * w10 + D[0] * w11, A[1] * w00 + B[1] * w01 + Cc[1] * w10 + D[1] * w11,
-              A[2] * w00 + B[2] * w01 + Cc[2] * w10 + D[2] * w11);
+    return env_lookup(e, d0, d1);
+}
+// InfiniteAreaLight::Le (infinite.cpp:77-81): the map at the spherical angles of the direction (geometry.h:935-942)
+__device__ __forceinline__ F3 env_le(const DevEnv &e, F3 d) {
+    F3 w = normalize3(xf_vector(e.w2l, d));
+    float p = atan2f(w.y, w.x);
+    float phi = (p < 0) ? (p + 2 * RT_PI) : p;
+    float theta = acosf(clampf(w.z, -1.f, 1.f));
+    return env_lookup(e, phi * RT_INV_2PI, theta * RT_INV_PI);
 }
 
 // reflection.h:11-69
@@ -404,7 +422,6 @@ __device__ __forceinline__ float sin2theta(F3 w) { return fmaxf(0.f, 1.f - cos2t
 __device__ __forceinline__ float sintheta(F3 w) { return sqrtf(sin2theta(w)); }
 __device__ __forceinline__ float tantheta(F3 w) { return sintheta(w) / w.z; }
 __device__ __forceinline__ float tan2theta(F3 w) { return sin2theta(w) / cos2theta(w); }
-__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ float cosphi(F3 w) { float s = sintheta(w); return (s == 0) ? 1.f : clampf(w.x / s, -1.f, 1.f); }
 __device__ __forceinline__ float sinphi(F3 w) { float s = sintheta(w); return (s == 0) ? 0.f : clampf(w.y / s, -1.f, 1.f); }
 __device__ __forceinline__ bool same_hemisphere(F3 a, F3 b) { return a.z * b.z > 0; }

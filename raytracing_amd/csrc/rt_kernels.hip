@@ -60,6 +60,7 @@ struct BounceStats { uint32_t n_queue, n_shadow, pad0, pad1; };
 struct PathQueue {   // SoA, capacity = cap
     float *ox, *oy, *oz, *dx, *dy, *dz, *tr, *tg, *tb;
     uint32_t *id, *state;   // state: depth | specular << 16
+    float *es;              // etaScale of PathIntegrator::Li (integrator.cpp:181,216-219); touched only under RenderParams::li
 };
 struct HitBuf { int *slot; float *t, *b0, *b1, *b2; };
 struct ShadowQueue { uint32_t *id; float *ox, *oy, *oz, *dx, *dy, *dz, *cr, *cg, *cb; };
@@ -75,6 +76,11 @@ struct RenderParams {
     uint32_t n_paths;
     int rr_shade;       // shading kernels take their chunks round robin (block_chunks)
     int merge_mirror;   // mirror paths are binned with the matte ones and shaded by k_shade<RT_MAT_MATTE>
+    // The estimators next to Li_re (only the kernels built with GEN read these, and the emission step of the extend kernels reads li):
+    int li;             // PathIntegrator::Li (integrator.cpp:175-229)
+    float rr_threshold; // its rrThreshold
+    int nee_mode;       // 0: UniformSampleOneLight and BSDF sampling in one launch; UniformSampleAllLights (integrator.cpp:26-51) takes one launch per
+    int nee_light;      // light with nee_mode 1 (direct light of light nee_light only) and a last one with nee_mode 2 (BSDF sampling only)
 };
 
 // ---------------------------------------------------------------- helpers --
@@ -314,6 +320,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderParams rp, PathQueue 
         uint32_t pos = blockIdx.x * segcap + (id - lo);
         q.ox[pos] = o.x; q.oy[pos] = o.y; q.oz[pos] = o.z; q.dx[pos] = d.x; q.dy[pos] = d.y; q.dz[pos] = d.z;
         q.tr[pos] = 1.f; q.tg[pos] = 1.f; q.tb[pos] = 1.f; q.id[pos] = id; q.state[pos] = 0;
+        if (rp.li) q.es[pos] = 1.f;
         lbuf[id] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (threadIdx.x == 0) counts[0].queue[blockIdx.x] = hi - lo;
@@ -384,16 +391,16 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend(DevScene sc, RenderParam
             hb.slot[i] = h.slot; hb.t[i] = h.t; hb.b0[i] = h.b0; hb.b1[i] = h.b1; hb.b2[i] = h.b2;
             // integrator.cpp:242-257
             F3 add = f3(0.f, 0.f, 0.f); bool terminal = false;
-            if (depth == 0 || spec || sc.n_lights == 0) {
+            if (depth == 0 || spec || (sc.n_lights == 0 && !rp.li)) {      // rp.li: integrator.cpp:185-192, emission does not end the path and there is no sky
                 if (found) {
                     int li = sc.slot_light[h.slot];
                     if (li >= 0) {
                         const DevLight &L = sc.lights[li];
                         float4 nf = sc.frames[3 * h.slot];
                         if (L.two_sided || dot3(f3(nf.x, nf.y, nf.z), -d) > 0) add = f3(L.Le[0], L.Le[1], L.Le[2]);   // light.h:73-75
-                        if (!black3(add)) terminal = true;
+                        if (!black3(add) && !rp.li) terminal = true;
                     }
-                } else if (sc.n_lights == 0) {
+                } else if (sc.n_lights == 0 && !rp.li) {
                     F3 ud = normalize3(d);
                     double t = 0.5 * (ud.y + 1.0);
                     float a = (float)(1.0 - t), b = (float)t;
@@ -469,16 +476,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_carry(DevScene sc, RenderPa
             const uint32_t state = q.state[i];
             const int depth = state & 0xFFFF; const bool spec = (state >> 16) & 1;
             F3 add = f3(0.f, 0.f, 0.f); bool terminal = false;
-            if (depth == 0 || spec || sc.n_lights == 0) {
+            if (depth == 0 || spec || (sc.n_lights == 0 && !rp.li)) {      // rp.li: integrator.cpp:185-192, emission does not end the path and there is no sky
                 if (found) {
                     int li = sc.slot_light[slot];
                     if (li >= 0) {
                         const DevLight &Lt = sc.lights[li];
                         float4 nf = sc.frames[3 * slot];
                         if (Lt.two_sided || dot3(f3(nf.x, nf.y, nf.z), -L.d) > 0) add = f3(Lt.Le[0], Lt.Le[1], Lt.Le[2]);   // light.h:73-75
-                        if (!black3(add)) terminal = true;
+                        if (!black3(add) && !rp.li) terminal = true;
                     }
-                } else if (sc.n_lights == 0) {
+                } else if (sc.n_lights == 0 && !rp.li) {
                     F3 ud = normalize3(L.d);
                     double t = 0.5 * (ud.y + 1.0);
                     float a = (float)(1.0 - t), b = (float)t;
@@ -831,15 +838,18 @@ __device__ __forceinline__ void copy_words_to_lds(void *dst, const void *src, in
 
 // What shading one path hands on: the shadow ray of next-event estimation with the radiance it carries if unoccluded, and the
 // next ray of the path with its throughput and state (depth | specular << 16).
-struct ShadeOut { bool has_shadow, has_next; uint32_t nstate; F3 so, sd, sc3, no, nd, nT; };
+struct ShadeOut { bool has_shadow, has_next; uint32_t nstate; F3 so, sd, sc3, no, nd, nT; float nes; };
 
 // Shading of one path at its hit (integrator.cpp:258-280): BSDF of material class MAT, next-event estimation, BSDF sampling,
 // Russian roulette.  `sc` may point its tables at LDS copies.
 // ENV: the scene may hold infinite area lights (a compile-time switch, so that the kernels of scenes without one do not carry the code).
-template <int MAT, bool ENV = false>
+// GEN: the estimators next to Li_re, chosen at run time through rp.li / rp.nee_mode (a compile-time switch, so that the kernels of the
+// reference's own estimator carry none of it): PathIntegrator::Li's light choice, roulette and etaScale, and the one-light-per-launch
+// steps of UniformSampleAllLights.
+template <int MAT, bool ENV = false, bool GEN = false>
 __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParams &rp, F3 o, F3 d, F3 T, uint32_t id, uint32_t state, int slot, float hit_t,
-                                           float hit_b0, float hit_b1, float hit_b2, ShadeOut &out) {
-    out.has_shadow = false; out.has_next = false; out.nstate = 0;
+                                           float hit_b0, float hit_b1, float hit_b2, ShadeOut &out, float eta_scale = 1.f) {
+    out.has_shadow = false; out.has_next = false; out.nstate = 0; out.nes = eta_scale;
     out.so = out.sd = out.sc3 = out.no = out.nd = out.nT = f3(0.f, 0.f, 0.f);
     int depth = state & 0xFFFF;
     const DevMaterial &m = sc.materials[sc.slot_material[slot]];
@@ -876,14 +886,32 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
                     float ad = fabsf(dot3(wiW, sp.n));
                     F3 beta = cdiv(f3(f.x * ad, f.y * ad, f.z * ad), pdf);
                     bool alive = true;
-                    if (depth > 3) {
-                        float qq = fmaxf(.05f, 1 - maxcomp3(beta));
-                        if (u32_to_unit(a3) < qq) alive = false;
-                        beta = cdiv(beta, 1 - qq);
+                    F3 nT;
+                    if (GEN && rp.li) {            // integrator.cpp:214-226: roulette on the whole path's throughput times etaScale
+                        nT = T * beta;
+                        float es = eta_scale;
+                        if (chosen.kind == 3) {    // specular transmission: BSDF::eta is the glass's index
+                            float eta = chosen.etaB;
+                            es *= (dot3(woW, sp.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+                        }
+                        out.nes = es;
+                        float mx = maxcomp3(f3(nT.x * es, nT.y * es, nT.z * es));
+                        if (mx < rp.rr_threshold && depth > 3) {
+                            float qq = fmaxf(.05f, 1 - mx);
+                            if (u32_to_unit(a3) < qq) alive = false;
+                            nT = cdiv(nT, 1 - qq);
+                        }
+                    } else {
+                        if (depth > 3) {
+                            float qq = fmaxf(.05f, 1 - maxcomp3(beta));
+                            if (u32_to_unit(a3) < qq) alive = false;
+                            beta = cdiv(beta, 1 - qq);
+                        }
+                        nT = T * beta;
                     }
                     if (alive) {
                         out.has_next = true;
-                        out.no = offset_ray_origin(sp.p, sp.n, wiW); out.nd = wiW; out.nT = T * beta;
+                        out.no = offset_ray_origin(sp.p, sp.n, wiW); out.nd = wiW; out.nT = nT;
                         out.nstate = (uint32_t)(depth + 1) | (lobe_is_specular(chosen.kind) ? (1u << 16) : 0u);
                     }
                 }
@@ -896,7 +924,7 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
     if (MAT == RT_MAT_MATTE && rp.merge_mirror && m.kind == RT_MAT_MIRROR) {
         Lobe lm, none; none.kind = 0;
         build_lobe<RT_MAT_MIRROR>(sc, m, sp.u, sp.v, lm);
-        if (lm.kind != 0) sample_bsdf(lm, none, 1);
+        if (lm.kind != 0 && (!GEN || rp.nee_mode != 1)) sample_bsdf(lm, none, 1);
     } else {
         Lobe lobe, lobe2;       // lobe2: PlasticMaterial (BSDF::Add order: Lambert, then microfacet) and the rough dielectric (reflection, then transmission)
         build_lobe<MAT>(sc, m, sp.u, sp.v, lobe);
@@ -911,12 +939,29 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
         }
         const int nlobes = ((MAT == RT_MAT_PLASTIC || MAT == RT_MAT_ROUGHGLASS) && lobe2.kind != 0) ? 2 : 1;
         // ---- next-event estimation: UniformSampleOneLight + EstimateDirect, integrator.cpp:53-102,259-264
-        if (lobe.kind != 0 && !lobe_is_specular(lobe.kind) && sc.n_lights > 0) {
+        const bool do_nee = !GEN || rp.nee_mode != 2, do_bsdf = !GEN || rp.nee_mode != 1;
+        if (do_nee && lobe.kind != 0 && !lobe_is_specular(lobe.kind) && sc.n_lights > 0) {
             int nL = sc.n_lights;
             int ln = min((int)(u32_to_unit(a0) * nL), nL - 1);
             float selPdf = 1.f / nL;
-            const DevLight &L = sc.lights[ln];
             float u0 = u32_to_unit(a1), u1 = u32_to_unit(a2);
+            if (GEN && rp.nee_mode == 1) {         // UniformSampleAllLights, this launch's light: EstimateDirect as it is (dividing by 1 changes no bit)
+                ln = rp.nee_light; selPdf = 1.f;
+                uint32_t c0 = pixel, c1 = sample, c2 = (uint32_t)depth, c3 = 2u + (uint32_t)ln;     // {uLight.x, uLight.y, -, -} of light ln
+                philox4x32(c0, c1, c2, c3, rp.k0, rp.k1);
+                u0 = u32_to_unit(c0); u1 = u32_to_unit(c1);
+            } else if (GEN && rp.li) {             // Distribution1D::SampleDiscrete over the uniform light distribution (sampling.h:40-48, pbrt.h:213-226)
+                float u = u32_to_unit(a0);
+                int first = 0, len = nL + 1;
+                while (len > 0) {
+                    int half = len >> 1, middle = first + half;
+                    if (sc.light_cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
+                    else len = half;
+                }
+                ln = min(max(first - 1, 0), nL - 1);
+                selPdf = 1.f / (sc.light_func_int * nL);
+            }
+            const DevLight &L = sc.lights[ln];
             if (ENV && L.kind == RT_LIGHT_INFINITE) {
                 // EstimateDirect (integrator.cpp:74-102) around InfiniteAreaLight::Sample_Li (infinite.cpp:83-106); the visibility
                 // segment ends at p + wi * 2 * worldRadius, a point without a normal, so that end gets no offset (interaction.h:27-36)
@@ -984,7 +1029,7 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
             }
             }
         }
-        if (lobe.kind != 0) sample_bsdf(lobe, lobe2, nlobes);
+        if (do_bsdf && lobe.kind != 0) sample_bsdf(lobe, lobe2, nlobes);
     }
 }
 
@@ -994,7 +1039,7 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
 // LDS copy of the pair records, instead of going through the shadow queue to k_shadow; the unoccluded light is added to
 // the path's radiance slot at once.  The tables live in dynamic LDS sized to the scene (shade_lds_bytes).
 // (matte and mirror are held at five waves per SIMD, which is also what their LDS allows; the heavier materials take the registers they need)
-template <int MAT, int TABLES, bool FUSE, bool ENV = false>
+template <int MAT, int TABLES, bool FUSE, bool ENV = false, bool GEN = false>
 __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIRROR || MAT == RT_MAT_METALROUGH) ? 5 : 4) void k_shade(DevScene sc_in, RenderParams rp, int bounce, PathQueue q, PathQueue qn, HitBuf hb, const uint32_t *cls_list,
                                                      uint32_t cap, uint32_t segcap, ShadowQueue sq, BounceCounts *counts, float4 *lbuf, BounceStats *stats) {
     constexpr bool LDS_TABLES = TABLES == 1;
@@ -1047,6 +1092,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
         bool active = j < cl.end;
         bool has_shadow = false, has_next = false;
         uint32_t id = 0, nstate = 0;
+        float nes = 1.f;
         F3 so = f3(0, 0, 0), sd = f3(0, 0, 0), sc3 = f3(0, 0, 0), no = f3(0, 0, 0), nd = f3(0, 0, 0), nT = f3(0, 0, 0);
         if (active) {
             while (j >= s_prefix[seg + 1]) seg++;
@@ -1056,7 +1102,11 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
             id = q.id[i];
             uint32_t state = q.state[i];
             ShadeOut out;
-            shade_path<MAT, ENV>(sc, rp, o, d, T, id, state, hb.slot[i], hb.t[i], hb.b0[i], hb.b1[i], hb.b2[i], out);
+            if (GEN) {
+                shade_path<MAT, ENV, true>(sc, rp, o, d, T, id, state, hb.slot[i], hb.t[i], hb.b0[i], hb.b1[i], hb.b2[i], out, rp.li ? q.es[i] : 1.f);
+                nes = out.nes;
+            } else
+                shade_path<MAT, ENV>(sc, rp, o, d, T, id, state, hb.slot[i], hb.t[i], hb.b0[i], hb.b1[i], hb.b2[i], out);
             has_shadow = out.has_shadow; has_next = out.has_next; nstate = out.nstate;
             so = out.so; sd = out.sd; sc3 = out.sc3; no = out.no; nd = out.nd; nT = out.nT;
         }
@@ -1084,11 +1134,40 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
         if (has_next) {
             qn.ox[npos] = no.x; qn.oy[npos] = no.y; qn.oz[npos] = no.z; qn.dx[npos] = nd.x; qn.dy[npos] = nd.y; qn.dz[npos] = nd.z;
             qn.tr[npos] = nT.x; qn.tg[npos] = nT.y; qn.tb[npos] = nT.z; qn.id[npos] = id; qn.state[npos] = nstate;
+            if (GEN && rp.li) qn.es[npos] = nes;
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) { bc->shadow[blockIdx.x] = s_out[0]; counts[bounce + 1].queue[blockIdx.x] = s_out[1]; }
     if (FUSE && (threadIdx.x & (RT_WAVE - 1)) == 0 && n_shadow_rays) atomicAdd(&stats[bounce].n_shadow, n_shadow_rays);   // statistics only
+}
+
+// PathIntegrator::Li only (integrator.cpp:188-191): a camera ray or a ray after a specular bounce that leaves the scene collects
+// Le of every infinite light, through the path's throughput.  A pass of its own over the bounce's queue after the extend kernel,
+// so that the extend kernels stay as they are.
+__global__ __launch_bounds__(RT_BLOCK) void k_env_escape(DevScene sc, int bounce, PathQueue q, HitBuf hb, uint32_t segcap, float4 *lbuf, BounceCounts *counts) {
+    __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE];
+    const uint32_t total = segment_prefix(counts[bounce].queue, s_prefix, s_wave);
+    const ChunkLoop cl = block_chunks(total, 0);
+    uint32_t seg = cl.start < cl.end ? segment_of(s_prefix, cl.start) : 0;
+    for (uint32_t base = cl.start; base < cl.end; base += cl.stride) {
+        uint32_t g = base + threadIdx.x;
+        if (g >= cl.end) continue;
+        while (g >= s_prefix[seg + 1]) seg++;
+        uint32_t i = seg * segcap + (g - s_prefix[seg]);
+        if (hb.slot[i] >= 0) continue;
+        uint32_t state = q.state[i];
+        if ((state & 0xFFFF) != 0 && !((state >> 16) & 1)) continue;
+        F3 d = f3(q.dx[i], q.dy[i], q.dz[i]), T = f3(q.tr[i], q.tg[i], q.tb[i]);
+        uint32_t id = q.id[i];
+        float4 L = lbuf[id];
+        for (int l = 0; l < sc.n_lights; ++l) {
+            if (sc.lights[l].kind != RT_LIGHT_INFINITE) continue;
+            F3 le = env_le(sc.envs[sc.lights[l].env], d);
+            L.x += T.x * le.x; L.y += T.y * le.y; L.z += T.z * le.z;
+        }
+        lbuf[id] = L;
+    }
 }
 
 // ------------------------------------------------------------------ finish --
@@ -1242,7 +1321,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, Sh
     __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE];
     BounceCounts *bc = counts + bounce;
     const uint32_t total = segment_prefix(bc->shadow, s_prefix, s_wave);
-    if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_shadow = total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_shadow += total;      // (one launch per light and bounce when every light is sampled)
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     TravStack st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.reset();
     PairStackT<8, true> gst; gst.lds_i = pst.lds_i; gst.lds_t = pst.lds_t; gst.cap = sc.quad_stack_cap;
@@ -1291,7 +1370,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_carry(DevScene sc, int boun
     __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE];
     BounceCounts *bc = counts + bounce;
     const uint32_t total = segment_prefix(bc->shadow, s_prefix, s_wave);
-    if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_shadow = total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_shadow += total;      // (one launch per light and bounce when every light is sampled)
     const uint32_t n_waves = gridDim.x * (RT_BLOCK / RT_WAVE), gwave = blockIdx.x * (RT_BLOCK / RT_WAVE) + threadIdx.x / RT_WAVE;
     const uint32_t n_chunks = (total + RT_WAVE - 1) / RT_WAVE;
     const uint32_t w_hi = (gwave < n_chunks ? (n_chunks - gwave + n_waves - 1) / n_waves : 0) * RT_WAVE;   // this wave's positions: logical [0, w_hi)
@@ -1480,7 +1559,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend_pl(DevScene sc, RenderPa
             uint32_t state = q.state[i];
             int depth = state & 0xFFFF; bool spec = (state >> 16) & 1;
             F3 add = f3(0.f, 0.f, 0.f); bool terminal = false;
-            if (depth == 0 || spec || sc.n_lights == 0) {
+            if (depth == 0 || spec || (sc.n_lights == 0 && !rp.li)) {      // rp.li: integrator.cpp:185-192, emission does not end the path and there is no sky
                 if (found) {
                     int li = sc.slot_light[slot];
                     if (li >= 0) {
@@ -1488,9 +1567,9 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend_pl(DevScene sc, RenderPa
                         const DevLight &Lt = sc.lights[li];
                         float4 nf = sc.frames[3 * slot];
                         if (Lt.two_sided || dot3(f3(nf.x, nf.y, nf.z), -d) > 0) add = f3(Lt.Le[0], Lt.Le[1], Lt.Le[2]);   // light.h:73-75
-                        if (!black3(add)) terminal = true;
+                        if (!black3(add) && !rp.li) terminal = true;
                     }
-                } else if (sc.n_lights == 0) {
+                } else if (sc.n_lights == 0 && !rp.li) {
                     F3 ud = normalize3(f3(q.dx[i], q.dy[i], q.dz[i]));
                     double t = 0.5 * (ud.y + 1.0);
                     float a = (float)(1.0 - t), b = (float)t;
@@ -1527,7 +1606,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_shadow_pl(DevScene sc, int boun
     const float4 *recs = MODE == RT_WALK_QUADS ? sc.quads : sc.pairs, *slots = sc.slots;
     BounceCounts *bc = counts + bounce;
     const uint32_t total = segment_prefix(bc->shadow, s_prefix, s_wave);
-    if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_shadow = total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_shadow += total;      // (one launch per light and bounce when every light is sampled)
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     PairStackT<RT_FRAME_RING> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
     st.cap = MODE == RT_WALK_QUADS ? sc.quad_stack_cap : RT_MAX_STACK;
@@ -1637,7 +1716,7 @@ struct rt_scene {
     std::vector<rt_bvh_node> nodes; std::vector<int32_t> order;
     int n_prims = 0;
     bool classes[RT_NUM_CLASSES] = {};
-    DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_envs, d_spill, d_pairs, d_quads;
+    DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_envs, d_light_cdf, d_spill, d_pairs, d_quads;
     int interior_depth = 0;
     std::vector<float> survival;     // fraction of a pass's paths still alive at each bounce, from the last pass that ran every bounce (k_finish)
     std::vector<DevBuf *> d_texels;
@@ -1909,7 +1988,8 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     for (int i = 0; i < d->n_env_lights; ++i) {
         const rt_env_light &E = d->env_lights[i]; DevEnv &D = envs[i]; memset(&D, 0, sizeof(D));
         if (!is_affine(E.light_to_world)) { set_error(ctx, "rt_scene_create: light transforms must be affine"); return -1; }
-        memcpy(D.l2w, E.light_to_world, 48);
+        if (!is_affine(E.world_to_light)) { set_error(ctx, "rt_scene_create: light transforms must be affine"); return -1; }
+        memcpy(D.l2w, E.light_to_world, 48); memcpy(D.w2l, E.world_to_light, 48);
         D.width = E.width; D.height = E.height; D.nu = E.nu; D.nv = E.nv; D.marginal_int = E.marginal_int; D.world_radius = E.world_radius;
         auto upf = [&](const float *src, size_t n, const float **dst) -> hipError_t {
             DevBuf *b = new DevBuf; sc->d_texels.push_back(b);
@@ -1939,6 +2019,17 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     HIP_OK(up(sc->d_tex, tex.data(), tex.size() * sizeof(DevTexture)));
     HIP_OK(up(sc->d_lights, lights.data(), lights.size() * sizeof(DevLight)));
     if (!envs.empty()) HIP_OK(up(sc->d_envs, envs.data(), envs.size() * sizeof(DevEnv)));
+    // Distribution1D over func = 1 per light, as UniformLightDistribution builds it (lightdistrib.cpp:12-15, sampling.h:16-27)
+    std::vector<float> light_cdf((size_t)d->n_lights + 1, 0.f);
+    float light_func_int = 0.f;
+    if (d->n_lights > 0) {
+        const int n = d->n_lights;
+        for (int i = 1; i < n + 1; ++i) light_cdf[i] = light_cdf[i - 1] + 1.f / n;
+        light_func_int = light_cdf[n];
+        if (light_func_int == 0) { for (int i = 1; i < n + 1; ++i) light_cdf[i] = float(i) / float(n); }
+        else for (int i = 1; i < n + 1; ++i) light_cdf[i] /= light_func_int;
+    }
+    HIP_OK(up(sc->d_light_cdf, light_cdf.data(), light_cdf.size() * sizeof(float)));
     // pair nodes: one 64-byte record per interior node with both children's boxes
     std::vector<int32_t> pairIndex(nn, -1);
     int n_pairs = 0;
@@ -2027,6 +2118,7 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     D.slot_light = (const int *)sc->d_slot_light.p; D.materials = (const DevMaterial *)sc->d_mats.p; D.textures = (const DevTexture *)sc->d_tex.p;
     D.lights = (const DevLight *)sc->d_lights.p; D.n_nodes = nn; D.n_slots = d->n_prims; D.n_lights = d->n_lights; D.pad = 0; D.n_materials = d->n_materials; D.n_textures = d->n_textures;
     D.pairs = (const float4 *)sc->d_pairs.p; D.n_pairs = n_pairs; D.envs = envs.empty() ? nullptr : (const DevEnv *)sc->d_envs.p;
+    D.n_envs = (int)envs.size(); D.light_cdf = (const float *)sc->d_light_cdf.p; D.light_func_int = light_func_int;
     memcpy(D.root_box, sc->nodes[0].bmin, 12); memcpy(D.root_box + 3, sc->nodes[0].bmax, 12);
     D.root_info = childInfo(0);
     D.quads = quads_ok ? (const float4 *)sc->d_quads.p : nullptr; D.n_quads = quads_ok ? n_quads : 0; D.quad_stack_cap = quad_cap;
@@ -2187,6 +2279,7 @@ static void bind_queue(PathQueue &q, void *base, size_t cap) {
     float *f = (float *)base;
     q.ox = f; q.oy = f + cap; q.oz = f + 2 * cap; q.dx = f + 3 * cap; q.dy = f + 4 * cap; q.dz = f + 5 * cap;
     q.tr = f + 6 * cap; q.tg = f + 7 * cap; q.tb = f + 8 * cap; q.id = (uint32_t *)(f + 9 * cap); q.state = (uint32_t *)(f + 10 * cap);
+    q.es = f + 11 * cap;
 }
 
 extern "C++" {
@@ -2208,6 +2301,11 @@ static bool shade_tables_in_lds(const DevScene &d) {
 template <int MAT>
 static void launch_shade(rt_scene *s, const RenderParams &rp, int bounce, const PathQueue &q, const PathQueue &qn, const HitBuf &hb, uint32_t cap,
                          uint32_t segcap, const ShadowQueue &sq, int nseg, bool fuse_shadow, float4 *lbuf, BounceStats *stats) {
+    if (rp.li || rp.nee_mode) {   // the estimators next to Li_re: one general variant (tables in global memory, either kind of light)
+        hipLaunchKernelGGL((k_shade<MAT, 0, false, true, true>), dim3(nseg), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
+                           cap, segcap, sq, (BounceCounts *)s->d_counters.p, lbuf, stats);
+        return;
+    }
     if (s->dev.envs) {        // scenes with an infinite area light: tables in global memory, shadow rays through the shadow queue
         hipLaunchKernelGGL((k_shade<MAT, 0, false, true>), dim3(nseg), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
                            cap, segcap, sq, (BounceCounts *)s->d_counters.p, lbuf, stats);
@@ -2242,13 +2340,13 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     if (npix > (1u << 30)) { set_error(ctx, "rt_render: image too large"); return -1; }
     int S = o->sample_end - o->sample_begin;
     // Paths per pass.  Every pass ends in a tail of near-empty bounces whose cost is fixed, so passes should be few and large:
-    // 188 bytes of queue state per path, 256 Mi paths = 50 GB of the 288 GB; never more than a third of what is free.
+    // 196 bytes of queue state per path, 256 Mi paths = 53 GB of the 288 GB; never more than a third of what is free.
     size_t pool = (size_t)o->pool_paths;
     if (o->pool_paths <= 0) {
         size_t free_b = 0, total_b = 0;
         HIP_OK(hipMemGetInfo(&free_b, &total_b));
-        free_b += this_->ws_cap * 188;                       // the workspace of an earlier call is reused
-        pool = std::min<size_t>((size_t)256 << 20, std::max<size_t>((size_t)1 << 20, free_b / 3 / 188));
+        free_b += this_->ws_cap * 196;                       // the workspace of an earlier call is reused
+        pool = std::min<size_t>((size_t)256 << 20, std::max<size_t>((size_t)1 << 20, free_b / 3 / 196));
     }
     int spb = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(S, 1), pool / npix));
     size_t n_pass = npix * (size_t)spb;
@@ -2268,7 +2366,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     size_t cap = segcap * nseg;
     if (cap >= (1ull << 31)) { set_error(ctx, "rt_render: pass too large"); return -1; }
     if (cap > this_->ws_cap) {
-        HIP_OK(this_->d_q[0].alloc(11 * cap * 4)); HIP_OK(this_->d_q[1].alloc(11 * cap * 4));
+        HIP_OK(this_->d_q[0].alloc(12 * cap * 4)); HIP_OK(this_->d_q[1].alloc(12 * cap * 4));
         HIP_OK(this_->d_hits.alloc(5 * cap * 4)); HIP_OK(this_->d_cls.alloc((size_t)RT_NUM_CLASSES * cap * 4));
         HIP_OK(this_->d_shadow.alloc(10 * cap * 4)); HIP_OK(this_->d_lbuf.alloc(cap * 16));
         this_->ws_cap = cap;
@@ -2294,6 +2392,10 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     RenderParams rp; memset(&rp, 0, sizeof(rp));
     memcpy(rp.r2c, cam->raster_to_camera, 64); memcpy(rp.c2w, cam->camera_to_world, 64);
     rp.width = W; rp.height = H; rp.strata_x = o->strata_x; rp.strata_y = o->strata_y; rp.max_depth = o->max_depth; rp.k0 = o->seed_lo; rp.k1 = o->seed_hi;
+    // the estimators next to Li_re run through the general shading kernels: no fused shadow rays, no k_finish
+    rp.li = (o->flags & RT_RENDER_LI) ? 1 : 0; rp.rr_threshold = o->rr_threshold;
+    const bool all_lights = (o->flags & RT_RENDER_ALL_LIGHTS) != 0 && this_->dev.n_lights > 0;
+    const bool general = rp.li || all_lights;
 
     rt_render_stats st; memset(&st, 0, sizeof(st));
     EventPair ev;
@@ -2330,9 +2432,9 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     // inside the shading kernel, where a wave runs its 64 shadow rays to completion.  Measured on the Cornell frame: shading alone
     // 128 ms + k_shadow_carry 93 ms (round-based k_shadow: 106 ms) against 210 ms for the fused kernel, so fusing stays the default
     const int shadow_carry_from = (lds_scene && round_pairs && !frame_old) ? env_int("RT_AMD_SHADOW_CARRY_FROM", 1 << 30) : 1 << 30;
-    const bool fuse_shadow = all_in_lds && shadow_carry_from > o->max_depth && env_int("RT_AMD_FUSE_SHADOW", 1) != 0;
+    const bool fuse_shadow = all_in_lds && !general && shadow_carry_from > o->max_depth && env_int("RT_AMD_FUSE_SHADOW", 1) != 0;
     // the late, near-empty bounces of LDS scenes in one launch (k_finish)
-    const bool use_finish = (all_in_lds || (!lds_scene && round_quads && !frame_old)) && !this_->dev.envs && env_int("RT_AMD_FINISH", 1) != 0;
+    const bool use_finish = (all_in_lds || (!lds_scene && round_quads && !frame_old)) && !this_->dev.envs && !general && env_int("RT_AMD_FINISH", 1) != 0;
     const int finish_chunks = env_int("RT_AMD_FINISH_CHUNKS", 2);
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
         int cur = std::min(spb, o->sample_end - s0);
@@ -2375,6 +2477,17 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                 hipLaunchKernelGGL(k_extend_pl<RT_WALK_PAIRS>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
                                    (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
             tm.mark(RT_TIME_TRACE);
+            if (rp.li && this_->dev.envs) {
+                hipLaunchKernelGGL(k_env_escape, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, q[cq], hb, useg, lbuf, counts);
+                tm.mark(RT_TIME_OTHER);
+            }
+            // UniformSampleAllLights: one shading launch (direct light of that light only) and one shadow launch per light, then the BSDF sampling
+            const int n_steps = (all_lights && b < o->max_depth) ? this_->dev.n_lights + 1 : 1;
+            for (int step = 0; step < n_steps; ++step) {
+            if (all_lights) {
+                rp.nee_mode = step < this_->dev.n_lights ? 1 : 2; rp.nee_light = step;
+                if (step > 0) HIP_OK(hipMemsetAsync(counts[b].shadow, 0, sizeof(counts[b].shadow), ctx->stream));
+            }
             if (b < o->max_depth) {
                 if (this_->classes[RT_MAT_MATTE]) launch_shade<RT_MAT_MATTE>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
                 if (this_->classes[RT_MAT_MIRROR] && !rp.merge_mirror) launch_shade<RT_MAT_MIRROR>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
@@ -2384,8 +2497,8 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                 if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
                 if (this_->classes[RT_MAT_ROUGHGLASS]) launch_shade<RT_MAT_ROUGHGLASS>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
                 tm.mark(RT_TIME_SHADE);
-                if (this_->dev.n_lights > 0 && !fuse_shadow) {
-                    if (frame_old || b < round_bounces) {
+                if (this_->dev.n_lights > 0 && !fuse_shadow && rp.nee_mode != 2) {
+                    if (frame_old || b < round_bounces || all_lights) {      // (k_shadow_pl borrows the hit buffer, which the next light's shading still reads)
                         if (b >= shadow_carry_from)
                             hipLaunchKernelGGL(k_shadow_carry, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats);
                         else if (lds_scene)
@@ -2402,6 +2515,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
                                            counts, bstats, (int *)this_->d_spill.p);
                     tm.mark(RT_TIME_SHADOW);
                 }
+            }
             }
             cq ^= 1;
         }

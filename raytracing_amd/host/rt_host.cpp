@@ -500,7 +500,8 @@ void PathIntegrator::Render(const Scene &scene, int image_width, int image_heigh
     cam.width = image_width; cam.height = image_height;
     rt_render_opts o; memset(&o, 0, sizeof(o));
     o.strata_x = sampler->xSamples; o.strata_y = sampler->ySamples; o.sample_begin = 0; o.sample_end = (int)sampler->samplesPerPixel;
-    o.max_depth = maxDepth; o.seed_lo = seedLo; o.seed_hi = seedHi;
+    o.max_depth = maxDepth; o.seed_lo = seedLo; o.seed_hi = seedHi; o.rr_threshold = rrThreshold;
+    o.flags = (estimateWithLi ? RT_RENDER_LI : 0) | (sampleAllLights ? RT_RENDER_ALL_LIGHTS : 0);
     lastSum.assign((size_t)image_width * image_height * 3, 0.f);
     // Every GPU the process sees takes a share of the samples of every pixel (RT_AMD_DEVICES=n caps the number); one GPU renders alone.
     int nDev = rt_device_count();

@@ -544,8 +544,11 @@ class PathIntegrator : public Integrator {
 public:
     PathIntegrator(int maxDepth, std::shared_ptr<const Camera> camera, std::shared_ptr<Sampler> sampler, const Bounds2i &pixelBounds,
                    Float rrThreshold = 1, const std::string &lightSampleStrategy = "spatial")
-        : maxDepth(maxDepth), camera(camera), sampler(sampler) {}
+        : maxDepth(maxDepth), camera(camera), sampler(sampler), rrThreshold(rrThreshold) {}
     void Render(const Scene &scene, int image_width, int image_height) override;
+    // Render estimates with Li_re, as the reference's Render does (integrator.cpp:332,362).  The reference also defines Li
+    // (integrator.cpp:175-229) and UniformSampleAllLights (:26-51) without calling either; these switches select them.
+    bool estimateWithLi = false, sampleAllLights = false;
     std::vector<float> lastSum;      // width*height*3, per-pixel radiance sums
     rt_render_stats lastStats;
     uint32_t seedLo = 0x243F6A88u, seedHi = 0x85A308D3u;
@@ -554,6 +557,7 @@ private:
     const int maxDepth;
     std::shared_ptr<const Camera> camera;
     std::shared_ptr<Sampler> sampler;
+    const Float rrThreshold;
 };
 
 // ---------------------------------------------------------- model loading --

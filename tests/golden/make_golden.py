@@ -154,6 +154,29 @@ def golden_for_scene(name, n_rays, img_specs, probe_n=512):
     osc.close(); scene.close()
 
 
+def golden_estimators(only):
+    """Images of the estimators the reference defines next to the one its Render calls: PathIntegrator::Li (estimator 1) and paths
+    whose direct lighting is UniformSampleAllLights (2: in the recursive form of Li_re, 3: in the iterative form of Li; see
+    AllLightsEstimator in oracle/ref_driver.cpp).  Stored as ref_est<k>_<scene>_<w>x<h>_<spp>spp_seed<A|B>.npy."""
+    cases = [(1, "cornell", 100, 16, 16), (1, "cornell_env", 100, 16, 16), (1, "spheres_env", 96, 20, 20), (1, "cornell_roughglass", 100, 16, 16),
+             (2, "cornell_metal", 100, 16, 16), (3, "cornell_env", 100, 16, 16)]
+    for est, name, w, sx, sy in cases:
+        if only and name not in only and "est" not in only:
+            continue
+        scene = ra.HostScene(name)
+        sbin = os.path.join(TMP, name + ".scene")
+        dump_scene(scene, sbin)
+        cpath = os.path.join(TMP, "%s_%d.cam" % (name, w))
+        open(cpath, "wb").write(cam_spec(name, w, w))
+        for tag, off in (("A", 0), ("B", 1 << 20)):
+            ipath = os.path.join(TMP, "img.f32")
+            run("render", sbin, cpath, sx, sy, 50, off, 8, ipath, est, 1.0)
+            img = np.fromfile(ipath, dtype=np.float32).reshape(w, w, 3)
+            np.save(os.path.join(GOLD, "ref_est%d_%s_%dx%d_%dspp_seed%s.npy" % (est, name, w, w, sx * sy, tag)), img)
+            print("   estimator", est, name, tag, "mean", img.mean(axis=(0, 1)) / (sx * sy))
+        scene.close()
+
+
 def golden_bvh_variants():
     """Trees of BVHAccel's other constructor arguments (bvh.h:17-20): SAH with maxPrimsInNode 1 and 4, EqualCounts."""
     for name in ("cornell", "sphere1", "helmet"):
@@ -229,6 +252,8 @@ if __name__ == "__main__":
     if not only or "kat" in only:
         golden_camera(); golden_transform()
     A, B = ("A", 0), ("B", 1 << 20)
+    if not only or "est" in only:
+        golden_estimators(only)
     if not only or "cornell" in only:
         golden_for_scene("cornell", 4096, [(64, 64, 4, 4, [A, B]), (100, 100, 16, 16, [A, B])])
     if not only or "cornell_plastic" in only:      # the short cube carries a PlasticMaterial (two-lobe BSDF, material.cpp:32-49)

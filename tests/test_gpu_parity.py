@@ -2,12 +2,15 @@
 reference renderer itself.  Traversal: bit-exact primitive ids and t.  Images: the HIP kernels and the oracle run the same
 counter-based sampler, so they agree per pixel up to libm differences (device sinf/cosf/atan2f vs glibc); against the
 reference's own sampler the agreement is statistical (mean within 0.5 %, RMSE below the reference's two-seed noise floor)."""
+import glob
 import os
+import re
 
 import numpy as np
 import pytest
 
 import raytracing_amd as ra
+from raytracing_amd import capi
 
 pytestmark = pytest.mark.gpu
 SCENES = ["cornell", "cornell_plastic", "cornell_metal", "cornell_roughglass", "cornell_env", "sphere1", "spheres2", "spheres3", "spheres_env", "helmet"]
@@ -231,6 +234,56 @@ def test_render_within_reference_noise_floor(name, w, spp, device_scene, host_sc
     rmse = np.sqrt(((img - best) ** 2).mean(axis=(0, 1)))
     tol = 0.005 if spp >= 64 else 0.01     # 16-spp images: the reference's own seeds differ by up to 0.3 %
     assert np.all(np.abs(img.mean(axis=(0, 1)) / best.mean(axis=(0, 1)) - 1) < tol), img.mean(axis=(0, 1)) / best.mean(axis=(0, 1))
+    assert np.all(rmse < floor), (rmse, floor)
+
+
+_EST_FLAGS = {1: capi.RT_RENDER_LI, 2: capi.RT_RENDER_ALL_LIGHTS, 3: capi.RT_RENDER_LI | capi.RT_RENDER_ALL_LIGHTS}
+
+
+@pytest.mark.parametrize("est,name", [(1, "cornell"), (1, "cornell_env"), (1, "spheres_env"), (1, "spheres2"), (1, "helmet"), (2, "cornell_metal"), (2, "helmet"),
+                                      (3, "cornell_env"), (3, "cornell")])
+def test_other_estimators_match_oracle_per_pixel(est, name, device_scene, oracle_scene, host_scene):
+    """PathIntegrator::Li (1) and UniformSampleAllLights inside the recursive (2) and the iterative (3) estimator, same sampler on both
+    sides: same ray counts and per-pixel sums as the oracle.  spheres2 has a glass sphere (etaScale) and no light: Li sees no sky, so
+    its image is black on both sides."""
+    cam = host_scene(name).camera(96, 96)
+    # The helmet stands on surfaces of albedo 1: a diffuse bounce multiplies the throughput by f cos / pdf = 1 up to rounding, so under
+    # Li's default rrThreshold of 1 the test 'max(throughput) < rrThreshold' is decided by the last bit (device and host sine / cosine
+    # differ there) and one path in 3000 takes the other side: 5 % roulette or none.  Away from that value the two sides agree.
+    rr = 0.8 if (name == "helmet" and est in (1, 3)) else 1.0
+    opts = ra.make_opts(4, 4, flags=_EST_FLAGS[est], rr_threshold=rr)
+    img, st = device_scene(name).render(cam, opts)
+    ref, cnt = oracle_scene(name).render(cam, opts, mode=1)
+    assert st.samples == 96 * 96 * 16 == cnt["samples"]
+    assert abs(int(st.rays_closest) - int(cnt["closest"])) <= 1e-4 * cnt["closest"] + 4
+    assert abs(int(st.rays_shadow) - int(cnt["shadow"])) <= 1e-4 * cnt["shadow"] + 4
+    if name == "spheres2":
+        assert not img.any() and not ref.any()
+        return
+    close = _rel_close(img, ref, 2e-3)
+    assert close.mean() > (0.99 if name == "helmet" else 0.995), close.mean()      # (helmet: 16 long paths per pixel, one flipped roulette shows)
+    assert np.all(np.abs(img.mean(axis=(0, 1)) / ref.mean(axis=(0, 1)) - 1) < 2e-3)
+    # and the estimator really is another one: its image differs from Li_re's in many pixels
+    base, _ = device_scene(name).render(cam, ra.make_opts(4, 4))
+    assert (np.abs(img - base).max(axis=2) > 1e-3 * (np.abs(base).max(axis=2) + 1e-6)).mean() > 0.2
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_est*_seedA.npy"))),
+                         ids=lambda p: os.path.basename(p)[4:-10])
+def test_other_estimators_within_reference_noise_floor(path, device_scene, host_scene):
+    """Against images the reference's own Li / UniformSampleAllLights code rendered with its own sampler (two seeds): mean within
+    0.5 %, RMSE against the mean of the two below the reference's seed-to-seed RMSE."""
+    m = re.match(r"ref_est(\d)_(\w+?)_(\d+)x(\d+)_(\d+)spp_seedA.npy", os.path.basename(path))
+    est, name, w, spp = int(m.group(1)), m.group(2), int(m.group(3)), int(m.group(5))
+    a = np.load(path) / spp
+    b = np.load(path.replace("seedA", "seedB")) / spp
+    sx = int(round(spp ** 0.5))
+    img, _ = device_scene(name).render(host_scene(name).camera(w, w), ra.make_opts(sx, spp // sx, flags=_EST_FLAGS[est]))
+    img = img / spp
+    best = 0.5 * (a + b)
+    floor = np.sqrt(((a - b) ** 2).mean(axis=(0, 1)))
+    rmse = np.sqrt(((img - best) ** 2).mean(axis=(0, 1)))
+    assert np.all(np.abs(img.mean(axis=(0, 1)) / best.mean(axis=(0, 1)) - 1) < 0.005), img.mean(axis=(0, 1)) / best.mean(axis=(0, 1))
     assert np.all(rmse < floor), (rmse, floor)
 
 

@@ -89,6 +89,24 @@ def test_rendered_images_bit_exact(path, host_scene, oracle_scene):
         assert np.array_equal(img, ref), "%s seed %s: max abs diff %g" % (name, tag, np.abs(img - ref).max())
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_est*_seedA.npy"))),
+                         ids=lambda p: os.path.basename(p)[4:-10])
+def test_other_estimators_bit_exact(path, host_scene, oracle_scene):
+    """PathIntegrator::Li (estimator 1: emission through the path throughput, infinite lights seen by escaping rays, the light picked
+    through the uniform Distribution1D, roulette on the whole throughput times etaScale) and UniformSampleAllLights inside the recursive
+    and the iterative estimator (2, 3): whole float images equal the reference's, two seeds each."""
+    m = re.match(r"ref_est(\d)_(\w+?)_(\d+)x(\d+)_(\d+)spp_seedA.npy", os.path.basename(path))
+    est, name, w, h, spp = int(m.group(1)), m.group(2), int(m.group(3)), int(m.group(4)), int(m.group(5))
+    sx = int(round(spp ** 0.5))
+    flags = {1: capi.RT_RENDER_LI, 2: capi.RT_RENDER_ALL_LIGHTS, 3: capi.RT_RENDER_LI | capi.RT_RENDER_ALL_LIGHTS}[est]
+    cam = host_scene(name).camera(w, h)
+    opts = ra.make_opts(sx, spp // sx, flags=flags)
+    for tag, off in (("A", 0), ("B", 1 << 20)):
+        ref = np.load(path.replace("seedA", "seed" + tag))
+        img, _ = oracle_scene(name).render(cam, opts, mode=0, seed_offset=off)
+        assert np.array_equal(img, ref), "%s estimator %d seed %s: max abs diff %g, %d pixels" % (name, est, tag, np.abs(img - ref).max(), (img != ref).any(axis=2).sum())
+
+
 def test_philox_sampler_agrees_statistically_with_reference_sampler(host_scene, oracle_scene, gold_dir):
     """The counter-based sampler replaces the reference's stream; its images must sit inside the reference's own
     two-seed noise: per-channel mean within 0.5 %, and RMSE against the reference's best estimate (the mean of its
