@@ -80,11 +80,20 @@ __device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y -
 __device__ __forceinline__ F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ F3 operator*(float s, F3 v) { return f3(s * v.x, s * v.y, s * v.z); }
 __device__ __forceinline__ F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+#ifdef RT_FAST_SHADE   /* experiment: hardware reciprocal / square root (1 ulp) in the shading arithmetic */
+__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ F3 vdiv(F3 v, float f) { float inv = __builtin_amdgcn_rcpf(f); return f3(v.x * inv, v.y * inv, v.z * inv); }
+__device__ __forceinline__ F3 cdiv(F3 v, float f) { float inv = __builtin_amdgcn_rcpf(f); return f3(v.x * inv, v.y * inv, v.z * inv); }
+#else
+__device__ __forceinline__ float fdiv(float a, float b) { return a / b; }
+__device__ __forceinline__ float fsqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ F3 vdiv(F3 v, float f) { float inv = 1.f / f; return f3(v.x * inv, v.y * inv, v.z * inv); }   // geometry.h:149-153
 __device__ __forceinline__ F3 cdiv(F3 v, float f) { return f3(v.x / f, v.y / f, v.z / f); }                               // spectrum.h:92-96
+#endif
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ float lensq(F3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
-__device__ __forceinline__ F3 normalize3(F3 v) { return vdiv(v, sqrtf(lensq(v))); }
+__device__ __forceinline__ F3 normalize3(F3 v) { return vdiv(v, fsqrt(lensq(v))); }
 __device__ __forceinline__ F3 cross3(F3 a, F3 b) {   // geometry.h:183-190: double intermediates
     double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
     return f3((float)((ay * bz) - (az * by)), (float)((az * bx) - (ax * bz)), (float)((ax * by) - (ay * bx)));

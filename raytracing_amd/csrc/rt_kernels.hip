@@ -75,7 +75,8 @@ struct RenderParams {
     uint32_t k0, k1;
     uint32_t n_paths;
     int rr_shade;       // shading kernels take their chunks round robin (block_chunks)
-    int merge_mirror;   // mirror paths are binned with the matte ones and shaded by k_shade<RT_MAT_MATTE>
+    int merge_mirror;   // 2: k_shade<RT_MAT_MATTE> shades the mirror list in a second loop of the same launch; 1: mirror paths are binned with the
+                        // matte ones and shaded by a branch of the matte code; 0: a launch of their own
     // The estimators next to Li_re (only the kernels built with GEN read these, and the emission step of the extend kernels reads li):
     int li;             // PathIntegrator::Li (integrator.cpp:175-229)
     float rr_threshold; // its rrThreshold
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend(DevScene sc, RenderParam
                 L.x += q.tr[i] * add.x; L.y += q.tg[i] * add.y; L.z += q.tb[i] * add.z;
                 lbuf[id] = L;
             }
-            if (!terminal) { cls = sc.materials[sc.slot_material[h.slot]].kind; if (rp.merge_mirror && cls == RT_MAT_MIRROR) cls = RT_MAT_MATTE; }
+            if (!terminal) { cls = sc.materials[sc.slot_material[h.slot]].kind; if (rp.merge_mirror == 1 && cls == RT_MAT_MIRROR) cls = RT_MAT_MATTE; }
         }
         // bin the path into the queue of its material class (one ballot per class present in the wave)
         for (int c = 0; c < RT_NUM_CLASSES; ++c) {
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_carry(DevScene sc, RenderPa
                 Lr.x += q.tr[i] * add.x; Lr.y += q.tg[i] * add.y; Lr.z += q.tb[i] * add.z;
                 lbuf[id] = Lr;
             }
-            if (!terminal) { cls = sc.materials[sc.slot_material[slot]].kind; if (rp.merge_mirror && cls == RT_MAT_MIRROR) cls = RT_MAT_MATTE; }
+            if (!terminal) { cls = sc.materials[sc.slot_material[slot]].kind; if (rp.merge_mirror == 1 && cls == RT_MAT_MIRROR) cls = RT_MAT_MATTE; }
             busy = false;
         }
         if (__ballot(fin) != 0)
@@ -921,7 +922,7 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
     // Mirror paths that k_extend binned with the matte ones (RenderParams::merge_mirror): MirrorMaterial has one specular lobe,
     // out.so there is out.no next-event estimation and the whole shading is one reflection (material.cpp:12-20, reflection.cpp:62-68).
     // Their own launch read its short index list with sparse gathers and cost 4 % of a Cornell frame.
-    if (MAT == RT_MAT_MATTE && rp.merge_mirror && m.kind == RT_MAT_MIRROR) {
+    if (MAT == RT_MAT_MATTE && rp.merge_mirror == 1 && m.kind == RT_MAT_MIRROR) {
         Lobe lm, none; none.kind = 0;
         build_lobe<RT_MAT_MIRROR>(sc, m, sp.u, sp.v, lm);
         if (lm.kind != 0 && (!GEN || rp.nee_mode != 1)) sample_bsdf(lm, none, 1);
@@ -940,7 +941,7 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
         const int nlobes = ((MAT == RT_MAT_PLASTIC || MAT == RT_MAT_ROUGHGLASS) && lobe2.kind != 0) ? 2 : 1;
         // ---- next-event estimation: UniformSampleOneLight + EstimateDirect, integrator.cpp:53-102,259-264
         const bool do_nee = !GEN || rp.nee_mode != 2, do_bsdf = !GEN || rp.nee_mode != 1;
-        if (do_nee && lobe.kind != 0 && !lobe_is_specular(lobe.kind) && sc.n_lights > 0) {
+        if (MAT != RT_MAT_MIRROR && do_nee && lobe.kind != 0 && !lobe_is_specular(lobe.kind) && sc.n_lights > 0) {
             int nL = sc.n_lights;
             int ln = min((int)(u32_to_unit(a0) * nL), nL - 1);
             float selPdf = 1.f / nL;
@@ -1080,13 +1081,19 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
     PairStackT<RT_FRAME_RING, false> pst; pst.lds_i = &s_stack[FUSE ? threadIdx.x : 0]; pst.lds_t = (float *)&s_stack[FUSE ? RT_FRAME_RING * RT_BLOCK + threadIdx.x : 0]; pst.reset();
     uint32_t n_shadow_rays = 0;
     BounceCounts *bc = counts + bounce;
-    const uint32_t *list = cls_list + (size_t)MAT * cap;
     // continue this block's segments where the previous class kernel of this bounce left them
     if (threadIdx.x == 0) { s_out[0] = bc->shadow[blockIdx.x]; s_out[1] = counts[bounce + 1].queue[blockIdx.x]; }
-    const uint32_t total = segment_prefix(bc->cls[MAT], s_prefix, s_wave);
+    const uint32_t seg_base = blockIdx.x * segcap;
+    // The matte kernel also shades the mirror list (merge_mirror == 2), in a second loop: one specular lobe, no next-event estimation
+    // (material.cpp:12-20, reflection.cpp:62-68).  A launch of its own over that short list cost 4 % of a Cornell frame, and one loop
+    // over both classes makes nearly every wave run both branches with most lanes idle in one of them.
+    // (two instances of the loop, so that each gets its own register allocation)
+    auto shade_list = [&](auto mat_tag) {
+    constexpr int M = decltype(mat_tag)::value;
+    const uint32_t *list = cls_list + (size_t)M * cap;
+    const uint32_t total = segment_prefix(bc->cls[M], s_prefix, s_wave);
     const ChunkLoop cl = block_chunks(total, rp.rr_shade);
     uint32_t seg = cl.start < cl.end ? segment_of(s_prefix, cl.start) : 0;
-    const uint32_t seg_base = blockIdx.x * segcap;
     for (uint32_t base = cl.start; base < cl.end; base += cl.stride) {
         uint32_t j = base + threadIdx.x;
         bool active = j < cl.end;
@@ -1103,14 +1110,17 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
             uint32_t state = q.state[i];
             ShadeOut out;
             if (GEN) {
-                shade_path<MAT, ENV, true>(sc, rp, o, d, T, id, state, hb.slot[i], hb.t[i], hb.b0[i], hb.b1[i], hb.b2[i], out, rp.li ? q.es[i] : 1.f);
+                shade_path<M, ENV, true>(sc, rp, o, d, T, id, state, hb.slot[i], hb.t[i], hb.b0[i], hb.b1[i], hb.b2[i], out, rp.li ? q.es[i] : 1.f);
                 nes = out.nes;
             } else
-                shade_path<MAT, ENV>(sc, rp, o, d, T, id, state, hb.slot[i], hb.t[i], hb.b0[i], hb.b1[i], hb.b2[i], out);
+                shade_path<M, ENV>(sc, rp, o, d, T, id, state, hb.slot[i], hb.t[i], hb.b0[i], hb.b1[i], hb.b2[i], out);
             has_shadow = out.has_shadow; has_next = out.has_next; nstate = out.nstate;
             so = out.so; sd = out.sd; sc3 = out.sc3; no = out.no; nd = out.nd; nT = out.nT;
         }
-        if (FUSE) {            // bvh.cpp:284-320 on the spot; tMax = 1 - ShadowEpsilon (interaction.h:27-32)
+        if (FUSE && M != RT_MAT_MIRROR) {            // bvh.cpp:284-320 on the spot; tMax = 1 - ShadowEpsilon (interaction.h:27-32)
+            // (Packing the block's shadow rays into full waves before the walk — about six paths in ten have one — was measured: through
+            // the idle stack area of LDS, three barriers per chunk, walkers rotated over the waves: 4 % slower than each wave walking
+            // the rays of its own 64 paths, because the waves of a block then move in lockstep.)
             n_shadow_rays += (uint32_t)__popcll(__ballot(has_shadow));
             bool lit = false;
             if (has_shadow) {
@@ -1123,7 +1133,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
                 Lr.x += sc3.x; Lr.y += sc3.y; Lr.z += sc3.z;
                 lbuf[id] = Lr;
             }
-        } else {
+        } else if (M != RT_MAT_MIRROR) {
             uint32_t spos = seg_base + block_append(has_shadow, &s_out[0]);
             if (has_shadow) {
                 sq.id[spos] = id; sq.ox[spos] = so.x; sq.oy[spos] = so.y; sq.oz[spos] = so.z; sq.dx[spos] = sd.x; sq.dy[spos] = sd.y; sq.dz[spos] = sd.z;
@@ -1136,6 +1146,12 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
             qn.tr[npos] = nT.x; qn.tg[npos] = nT.y; qn.tb[npos] = nT.z; qn.id[npos] = id; qn.state[npos] = nstate;
             if (GEN && rp.li) qn.es[npos] = nes;
         }
+    }
+    };
+    shade_list(std::integral_constant<int, MAT>{});
+    if (MAT == RT_MAT_MATTE && rp.merge_mirror == 2) {
+        __syncthreads();        // every thread is done with the first list's prefix sums
+        shade_list(std::integral_constant<int, RT_MAT_MIRROR>{});
     }
     __syncthreads();
     if (threadIdx.x == 0) { bc->shadow[blockIdx.x] = s_out[0]; counts[bounce + 1].queue[blockIdx.x] = s_out[1]; }
@@ -1583,7 +1599,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend_pl(DevScene sc, RenderPa
                 Lr.x += q.tr[i] * add.x; Lr.y += q.tg[i] * add.y; Lr.z += q.tb[i] * add.z;
                 lbuf[id] = Lr;
             }
-            if (!terminal) { cls = sc.materials[sc.slot_material[slot]].kind; if (rp.merge_mirror && cls == RT_MAT_MIRROR) cls = RT_MAT_MATTE; }
+            if (!terminal) { cls = sc.materials[sc.slot_material[slot]].kind; if (rp.merge_mirror == 1 && cls == RT_MAT_MIRROR) cls = RT_MAT_MATTE; }
         }
         for (int c = 0; c < RT_NUM_CLASSES; ++c) {
             bool mine = (cls == c);
@@ -2422,7 +2438,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     const int rr_extend = env_int("RT_AMD_RR_EXTEND", 1) ? 2 : 0;
     const int rr_shadow = env_int("RT_AMD_RR_SHADOW", 1) ? 2 : 0;
     rp.rr_shade = env_int("RT_AMD_RR_SHADE", 0);
-    rp.merge_mirror = (this_->classes[RT_MAT_MATTE] && this_->classes[RT_MAT_MIRROR] && env_int("RT_AMD_MERGE_MIRROR", 1)) ? 1 : 0;
+    rp.merge_mirror = (this_->classes[RT_MAT_MATTE] && this_->classes[RT_MAT_MIRROR]) ? std::max(0, std::min(2, env_int("RT_AMD_MERGE_MIRROR", 2))) : 0;
     // incoherent bounces of LDS scenes: lanes carry long rays over and refill (k_extend_carry); camera rays stay round-based
     const int carry_from = env_int("RT_AMD_CARRY_FROM", 1);
     // shadow rays traced inside the shading kernels: scenes whose tree and tables both sit in LDS

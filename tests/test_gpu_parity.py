@@ -375,7 +375,7 @@ def test_frame_walks_give_identical_images(name, w, device_scene, host_scene, mo
                 # shadow rays through the shadow queue instead of inside the shading kernel; no carry-over of long rays; contiguous
                 # shares instead of round-robin chunks; mirror paths in a class list and launch of their own; shading chunks round robin
                 {"RT_AMD_FUSE_SHADOW": "0"}, {"RT_AMD_SHADOW_CARRY_FROM": "0"}, {"RT_AMD_SHADOW_CARRY_FROM": "2"}, {"RT_AMD_CARRY_FROM": "1000"}, {"RT_AMD_RR_EXTEND": "0", "RT_AMD_RR_SHADOW": "0"},
-                {"RT_AMD_MERGE_MIRROR": "0"}, {"RT_AMD_RR_SHADE": "1"}, {"RT_AMD_SHADE_GLOBAL_TABLES": "1"},
+                {"RT_AMD_MERGE_MIRROR": "0"}, {"RT_AMD_MERGE_MIRROR": "1"}, {"RT_AMD_RR_SHADE": "1"}, {"RT_AMD_SHADE_GLOBAL_TABLES": "1"},
                 # every bounce through its own launches instead of k_finish for the late ones (the first render of a scene learns the
                 # switch-over bounce, so the renders after it use k_finish unless told otherwise)
                 {"RT_AMD_FINISH": "0"},
