@@ -80,20 +80,35 @@ __device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y -
 __device__ __forceinline__ F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ F3 operator*(float s, F3 v) { return f3(s * v.x, s * v.y, s * v.z); }
 __device__ __forceinline__ F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
-#ifdef RT_FAST_SHADE   /* experiment: hardware reciprocal / square root (1 ulp) in the shading arithmetic */
-__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ F3 vdiv(F3 v, float f) { float inv = __builtin_amdgcn_rcpf(f); return f3(v.x * inv, v.y * inv, v.z * inv); }
-__device__ __forceinline__ F3 cdiv(F3 v, float f) { float inv = __builtin_amdgcn_rcpf(f); return f3(v.x * inv, v.y * inv, v.z * inv); }
-#else
-__device__ __forceinline__ float fdiv(float a, float b) { return a / b; }
-__device__ __forceinline__ float fsqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ F3 vdiv(F3 v, float f) { float inv = 1.f / f; return f3(v.x * inv, v.y * inv, v.z * inv); }   // geometry.h:149-153
 __device__ __forceinline__ F3 cdiv(F3 v, float f) { return f3(v.x / f, v.y / f, v.z / f); }                               // spectrum.h:92-96
+// Division and square root for the VALUES of the shading arithmetic every path computes (light pdfs, BSDF value times cosine over
+// pdf, throughput, roulette weights): the hardware reciprocal and square root, 1 ulp, two instructions instead of the ten to thirteen of
+// the correctly rounded sequences.  Nothing that decides where a path goes uses these: the slab, triangle and sphere tests, inverse
+// ray directions, camera rays, interaction frames and sampled directions keep IEEE '/' and sqrtf (which hipcc rounds correctly) — a
+// last-bit change of a direction moves a hit across a triangle edge once in about 10^4 hits, which a per-pixel comparison with the
+// CPU restatement shows on a fine mesh — and so do the microfacet lobes, whose sampling formulas amplify a last-bit difference.
+// -DRT_SHADE_IEEE=1 makes these IEEE too.
+#ifndef RT_SHADE_IEEE
+#define RT_SHADE_IEEE 0
+#endif
+#if RT_SHADE_IEEE
+__device__ __forceinline__ float frcp(float b) { return 1.f / b; }
+__device__ __forceinline__ float fdiv(float a, float b) { return a / b; }
+__device__ __forceinline__ float fsqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ float frsq(float x) { return 1.f / sqrtf(x); }
+__device__ __forceinline__ F3 cdiv_s(F3 v, float f) { return cdiv(v, f); }
+#else
+__device__ __forceinline__ float frcp(float b) { return __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ F3 cdiv_s(F3 v, float f) { float inv = __builtin_amdgcn_rcpf(f); return f3(v.x * inv, v.y * inv, v.z * inv); }
 #endif
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ float lensq(F3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
-__device__ __forceinline__ F3 normalize3(F3 v) { return vdiv(v, fsqrt(lensq(v))); }
+__device__ __forceinline__ F3 normalize3(F3 v) { return vdiv(v, sqrtf(lensq(v))); }
+__device__ __forceinline__ F3 normalize3_s(F3 v) { float inv = frsq(lensq(v)); return f3(v.x * inv, v.y * inv, v.z * inv); }
 __device__ __forceinline__ F3 cross3(F3 a, F3 b) {   // geometry.h:183-190: double intermediates
     double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
     return f3((float)((ay * bz) - (az * by)), (float)((az * bx) - (ax * bz)), (float)((ax * by) - (ay * bx)));
@@ -124,6 +139,20 @@ __device__ __forceinline__ void philox4x32(uint32_t &c0, uint32_t &c1, uint32_t 
 // RNG::UniformFloat's integer->float mapping (rng.h:38-45)
 __device__ __forceinline__ float u32_to_unit(uint32_t v) { return fminf(RT_ONE_MINUS_EPS, (float)v * 2.3283064365386963e-10f); }
 
+// Unsigned division by a number that is the same for the whole launch (Granlund & Montgomery 1994): the host precomputes
+// l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1; then n / d = (t + ((n - t) >> min(l, 1))) >> max(l - 1, 0) with t = mulhi(m, n),
+// exact for every 32-bit n.  Five instructions instead of the forty of a general 32-bit division.
+struct FastDiv { uint32_t m, s1, s2, d; };
+__host__ __device__ inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f; f.d = d;
+    uint32_t l = 0; while (l < 32 && (1ull << l) < d) ++l;
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.s1 = l < 1 ? l : 1; f.s2 = l > 1 ? l - 1 : 0;
+    return f;
+}
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv &f) { uint32_t t = __umulhi(f.m, n); return (t + ((n - t) >> f.s1)) >> f.s2; }
+__device__ __forceinline__ uint32_t fast_mod(uint32_t n, const FastDiv &f) { return n - fast_div(n, f) * f.d; }
+
 // Stateless permutation of {0..l-1} (Kensler 2013, "Correlated Multi-Jittered Sampling").
 __device__ __forceinline__ uint32_t kensler_permute(uint32_t i, uint32_t l, uint32_t p) {
     uint32_t w = l - 1;
@@ -134,6 +163,17 @@ __device__ __forceinline__ uint32_t kensler_permute(uint32_t i, uint32_t l, uint
         i ^= (i & w) >> 2; i *= 0x9e501cc3; i ^= (i & w) >> 2; i *= 0xc860a3df; i &= w; i ^= i >> 5;
     } while (i >= l);
     return (i + p) % l;
+}
+__device__ __forceinline__ uint32_t kensler_permute(uint32_t i, const FastDiv &fl, uint32_t p) {      // the same, l = fl.d
+    const uint32_t l = fl.d;
+    uint32_t w = l - 1;
+    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+    do {
+        i ^= p; i *= 0xe170893d; i ^= p >> 16; i ^= (i & w) >> 4; i ^= p >> 8; i *= 0x0929eb3f; i ^= p >> 23;
+        i ^= (i & w) >> 1; i *= 1 | p >> 27; i *= 0x6935fa69; i ^= (i & w) >> 11; i *= 0x74dcb303;
+        i ^= (i & w) >> 2; i *= 0x9e501cc3; i ^= (i & w) >> 2; i *= 0xc860a3df; i &= w; i ^= i >> 5;
+    } while (i >= l);
+    return fast_mod(i + p, fl);
 }
 
 // ------------------------------------------------------------ intersection --
@@ -361,7 +401,11 @@ __device__ __forceinline__ F3 eval_texture(const DevTexture &t, float u, float v
     float fs = floorf(s), ft = floorf(tt);
     int s0 = (int)fs, t0 = (int)ft;
     float ds = s - s0, dt = tt - t0;
-    int sa = mod_wrap(s0, t.width), sb = mod_wrap(s0 + 1, t.width), ta = mod_wrap(t0, t.height), tb = mod_wrap(t0 + 1, t.height);
+    int sa, sb, ta, tb;
+    if (((t.width & (t.width - 1)) | (t.height & (t.height - 1))) == 0) {       // powers of two (what MIPMap's constructor makes of every image,
+        sa = s0 & (t.width - 1); sb = (s0 + 1) & (t.width - 1);                   // mipmap.h:70-121): the Repeat wrap is a mask, negative texels included
+        ta = t0 & (t.height - 1); tb = (t0 + 1) & (t.height - 1);
+    } else { sa = mod_wrap(s0, t.width); sb = mod_wrap(s0 + 1, t.width); ta = mod_wrap(t0, t.height); tb = mod_wrap(t0 + 1, t.height); }
     const float *A = t.texels + 3 * ((size_t)ta * t.width + sa), *B = t.texels + 3 * ((size_t)tb * t.width + sa);
     const float *Cc = t.texels + 3 * ((size_t)ta * t.width + sb), *D = t.texels + 3 * ((size_t)tb * t.width + sb);
     float w00 = (1 - ds) * (1 - dt), w01 = (1 - ds) * dt, w10 = ds * (1 - dt), w11 = ds * dt;

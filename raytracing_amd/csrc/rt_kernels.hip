@@ -75,6 +75,7 @@ struct RenderParams {
     uint32_t k0, k1;
     uint32_t n_paths;
     int rr_shade;       // shading kernels take their chunks round robin (block_chunks)
+    FastDiv d_spb, d_width, d_strata_x, d_nstrata;      // divisions by spb, width, strata_x, strata_x * strata_y
     int merge_mirror;   // 2: k_shade<RT_MAT_MATTE> shades the mirror list in a second loop of the same launch; 1: mirror paths are binned with the
                         // matte ones and shaded by a branch of the matte code; 0: a launch of their own
     // The estimators next to Li_re (only the kernels built with GEN read these, and the emission step of the extend kernels reads li):
@@ -303,17 +304,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RenderParams rp, PathQueue 
     uint32_t n = rp.n_paths, lo, hi;
     block_share(n, lo, hi);
     for (uint32_t id = lo + threadIdx.x; id < hi; id += RT_BLOCK) {
-        uint32_t pixel = id / (uint32_t)rp.spb, sample = (uint32_t)rp.sample0 + id % (uint32_t)rp.spb;
+        uint32_t pixel = fast_div(id, rp.d_spb), sample = (uint32_t)rp.sample0 + (id - pixel * (uint32_t)rp.spb);
         uint32_t c0 = pixel, c1 = sample, c2 = 0xFFFFFFFFu, c3 = 0;
         philox4x32(c0, c1, c2, c3, rp.k0, rp.k1);
         uint32_t p0 = pixel, p1 = 0xFFFFFFFFu, p2 = 0xFFFFFFFFu, p3 = 0;
         philox4x32(p0, p1, p2, p3, rp.k0, rp.k1);
-        uint32_t nstrata = (uint32_t)(rp.strata_x * rp.strata_y);
-        uint32_t s = kensler_permute(sample % nstrata, nstrata, p0);
-        int sx = (int)(s % (uint32_t)rp.strata_x), sy = (int)(s / (uint32_t)rp.strata_x);
+        uint32_t s = kensler_permute(fast_mod(sample, rp.d_nstrata), rp.d_nstrata, p0);
+        int sy = (int)fast_div(s, rp.d_strata_x), sx = (int)(s - (uint32_t)sy * (uint32_t)rp.strata_x);
         float ddx = 1.f / rp.strata_x, ddy = 1.f / rp.strata_y;
         float fx = fminf((sx + u32_to_unit(c0)) * ddx, RT_ONE_MINUS_EPS), fy = fminf((sy + u32_to_unit(c1)) * ddy, RT_ONE_MINUS_EPS);
-        int px = (int)(pixel % (uint32_t)rp.width), py = (int)(pixel / (uint32_t)rp.width);
+        int py = (int)fast_div(pixel, rp.d_width), px = (int)(pixel - (uint32_t)py * (uint32_t)rp.width);
         F3 pCamera = xf_point_proj(rp.r2c, f3((float)px + fx, (float)py + fy, 0.f));
         F3 dir = normalize3(pCamera);
         F3 o = xf_point_proj(rp.c2w, f3(0.f, 0.f, 0.f));
@@ -690,7 +690,7 @@ __device__ __forceinline__ F3 lobe_sample(const Lobe &l, F3 wo, float u0, float 
     if (l.kind == 2) {
         wi = f3(-wo.x, -wo.y, wo.z);
         pdf = 1;
-        return cdiv(f3(1.f * l.R.x, 1.f * l.R.y, 1.f * l.R.z), fabsf(wi.z));
+        return cdiv_s(f3(1.f * l.R.x, 1.f * l.R.y, 1.f * l.R.z), fabsf(wi.z));
     }
     if (l.kind == 3) {
         bool entering = wo.z > 0;
@@ -706,9 +706,9 @@ __device__ __forceinline__ F3 lobe_sample(const Lobe &l, F3 wo, float u0, float 
         pdf = 1;
         float fr = fr_dielectric(wi.z, 1.f, l.etaB);
         F3 ft = f3(l.R.x * (1.f - fr), l.R.y * (1.f - fr), l.R.z * (1.f - fr));
-        float sc = (etaI * etaI) / (etaT * etaT);
+        float sc = fdiv(etaI * etaI, etaT * etaT);
         ft = f3(ft.x * sc, ft.y * sc, ft.z * sc);
-        return cdiv(ft, fabsf(wi.z));
+        return cdiv_s(ft, fabsf(wi.z));
     }
     if (l.kind == 4 || l.kind == 5 || l.kind == 6) {
         if (wo.z == 0) return f3(0.f, 0.f, 0.f);
@@ -856,7 +856,7 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
     const DevMaterial &m = sc.materials[sc.slot_material[slot]];
     SurfacePoint sp;
     surface_point(sc, slot, o, d, hit_t, hit_b0, hit_b1, hit_b2, material_needs_uv<MAT>(sc, m), sp);
-    uint32_t pixel = id / (uint32_t)rp.spb, sample = (uint32_t)rp.sample0 + id % (uint32_t)rp.spb;
+    uint32_t pixel = fast_div(id, rp.d_spb), sample = (uint32_t)rp.sample0 + (id - pixel * (uint32_t)rp.spb);
     uint32_t a0 = pixel, a1 = sample, a2 = (uint32_t)depth, a3 = 0;   // {light pick, uLight.x, uLight.y, roulette}
     philox4x32(a0, a1, a2, a3, rp.k0, rp.k1);
     // ---- BSDF sampling, integrator.cpp:265-279 + BSDF::Sample_f reflection.cpp:173-217 (as a lambda: the matte kernel runs it
@@ -885,7 +885,7 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
                 }
                 if (!black3(f) && pdf != 0.f) {
                     float ad = fabsf(dot3(wiW, sp.n));
-                    F3 beta = cdiv(f3(f.x * ad, f.y * ad, f.z * ad), pdf);
+                    F3 beta = cdiv_s(f3(f.x * ad, f.y * ad, f.z * ad), pdf);
                     bool alive = true;
                     F3 nT;
                     if (GEN && rp.li) {            // integrator.cpp:214-226: roulette on the whole path's throughput times etaScale
@@ -900,13 +900,13 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
                         if (mx < rp.rr_threshold && depth > 3) {
                             float qq = fmaxf(.05f, 1 - mx);
                             if (u32_to_unit(a3) < qq) alive = false;
-                            nT = cdiv(nT, 1 - qq);
+                            nT = cdiv_s(nT, 1 - qq);
                         }
                     } else {
                         if (depth > 3) {
                             float qq = fmaxf(.05f, 1 - maxcomp3(beta));
                             if (u32_to_unit(a3) < qq) alive = false;
-                            beta = cdiv(beta, 1 - qq);
+                            beta = cdiv_s(beta, 1 - qq);
                         }
                         nT = T * beta;
                     }
@@ -944,7 +944,7 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
         if (MAT != RT_MAT_MIRROR && do_nee && lobe.kind != 0 && !lobe_is_specular(lobe.kind) && sc.n_lights > 0) {
             int nL = sc.n_lights;
             int ln = min((int)(u32_to_unit(a0) * nL), nL - 1);
-            float selPdf = 1.f / nL;
+            float selPdf = frcp((float)nL);
             float u0 = u32_to_unit(a1), u1 = u32_to_unit(a2);
             if (GEN && rp.nee_mode == 1) {         // UniformSampleAllLights, this launch's light: EstimateDirect as it is (dividing by 1 changes no bit)
                 ln = rp.nee_light; selPdf = 1.f;
@@ -982,13 +982,13 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
                         F3 far_end = sp.p + (2 * E.world_radius) * wi;
                         F3 origin = offset_ray_origin(sp.p, sp.n, far_end - sp.p);
                         F3 target = offset_ray_origin(far_end, f3(0.f, 0.f, 0.f), origin - far_end);
-                        F3 Ld = cdiv(cdiv(f * Li, pdf), selPdf);
+                        F3 Ld = cdiv_s(cdiv_s(f * Li, pdf), selPdf);
                         out.has_shadow = true; out.so = origin; out.sd = target - origin; out.sc3 = T * Ld;
                     }
                 }
             } else {
             F3 p0 = f3(L.p0[0], L.p0[1], L.p0[2]), p1 = f3(L.p1[0], L.p1[1], L.p1[2]), p2 = f3(L.p2[0], L.p2[1], L.p2[2]);
-            float su0 = sqrtf(u0);
+            float su0 = fsqrt(u0);
             float lb0 = 1 - su0, lb1 = u1 * su0;                       // UniformSampleTriangle, sampling.cpp:108-111
             F3 lp = (lb0 * p0 + lb1 * p1) + (1 - lb0 - lb1) * p2;      // Triangle::Sample, triangle.cpp:229-248
             F3 lnrm = f3(L.n[0], L.n[1], L.n[2]);
@@ -997,18 +997,18 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
                 F3 ns = (lb0 * f3(L.vn[0], L.vn[1], L.vn[2]) + lb1 * f3(L.vn[3], L.vn[4], L.vn[5])) + w2 * f3(L.vn[6], L.vn[7], L.vn[8]);
                 if (dot3(lnrm, ns) < 0.f) lnrm = -lnrm;
             }
-            float pdf = 1 / L.area;
+            float pdf = frcp(L.area);
             F3 wi = lp - sp.p;                                          // Shape::Sample(ref,u,pdf), shape.cpp:20-31
             if (lensq(wi) == 0) pdf = 0;
             else {
-                wi = normalize3(wi);
-                pdf *= lensq(sp.p - lp) / fabsf(dot3(lnrm, -wi));
+                wi = normalize3_s(wi);
+                pdf *= fdiv(lensq(sp.p - lp), fabsf(dot3(lnrm, -wi)));
                 if (isinf(pdf)) pdf = 0.f;
             }
             F3 Li = f3(0.f, 0.f, 0.f);                                  // DiffuseAreaLight::Sample_Li, light.cpp:43-54
             if (pdf == 0 || lensq(lp - sp.p) == 0) pdf = 0;
             else {
-                wi = normalize3(lp - sp.p);
+                wi = normalize3_s(lp - sp.p);
                 if (L.two_sided || dot3(lnrm, -wi) > 0) Li = f3(L.Le[0], L.Le[1], L.Le[2]);
             }
             if (pdf > 0 && !black3(Li)) {
@@ -1024,7 +1024,7 @@ __device__ __forceinline__ void shade_path(const DevScene &sc, const RenderParam
                 if (!black3(f)) {
                     F3 origin = offset_ray_origin(sp.p, sp.n, lp - sp.p);     // Interaction::SpawnRayTo, interaction.h:27-32
                     F3 target = offset_ray_origin(lp, lnrm, origin - lp);
-                    F3 Ld = cdiv(cdiv(f * Li, pdf), selPdf);
+                    F3 Ld = cdiv_s(cdiv_s(f * Li, pdf), selPdf);
                     out.has_shadow = true; out.so = origin; out.sd = target - origin; out.sc3 = T * Ld;
                 }
             }
@@ -2408,6 +2408,9 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     RenderParams rp; memset(&rp, 0, sizeof(rp));
     memcpy(rp.r2c, cam->raster_to_camera, 64); memcpy(rp.c2w, cam->camera_to_world, 64);
     rp.width = W; rp.height = H; rp.strata_x = o->strata_x; rp.strata_y = o->strata_y; rp.max_depth = o->max_depth; rp.k0 = o->seed_lo; rp.k1 = o->seed_hi;
+    rp.d_width = make_fastdiv((uint32_t)W); rp.d_strata_x = make_fastdiv((uint32_t)o->strata_x);
+    if ((int64_t)o->strata_x * o->strata_y >= (1ll << 31)) { set_error(ctx, "rt_render: too many strata"); return -1; }
+    rp.d_nstrata = make_fastdiv((uint32_t)(o->strata_x * o->strata_y));
     // the estimators next to Li_re run through the general shading kernels: no fused shadow rays, no k_finish
     rp.li = (o->flags & RT_RENDER_LI) ? 1 : 0; rp.rr_threshold = o->rr_threshold;
     const bool all_lights = (o->flags & RT_RENDER_ALL_LIGHTS) != 0 && this_->dev.n_lights > 0;
@@ -2454,7 +2457,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     const int finish_chunks = env_int("RT_AMD_FINISH_CHUNKS", 2);
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
         int cur = std::min(spb, o->sample_end - s0);
-        rp.spb = cur; rp.sample0 = s0; rp.n_paths = (uint32_t)(npix * (size_t)cur);
+        rp.spb = cur; rp.d_spb = make_fastdiv((uint32_t)cur); rp.sample0 = s0; rp.n_paths = (uint32_t)(npix * (size_t)cur);
         HIP_OK(hipMemsetAsync(bstats, 0, stats_bytes, ctx->stream));
         tm.begin_pass();
         hipLaunchKernelGGL(k_raygen, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, rp, q[0], useg, lbuf, counts);
