@@ -170,9 +170,11 @@ typedef struct rt_render_opts {
     int32_t  sample_begin, sample_end; /* this call renders samples [begin,end) of every pixel */
     int32_t  max_depth;            /* PathIntegrator maxDepth (RayTracing.cpp:431 passes 50) */
     uint32_t seed_lo, seed_hi;     /* Philox key */
-    int32_t  pool_paths;           /* path slots kept in flight; 0 = library default */
+    int32_t  pool_paths;           /* path slots kept in flight (200 bytes of device memory each); 0 = library default: half of the free
+                                      device memory, at most 2^30, halved again if the allocation fails */
     int32_t  flags;                /* RT_RENDER_* */
-    float    rr_threshold;         /* PathIntegrator's rrThreshold (integrator.h:72, default 1); read only under RT_RENDER_LI */
+    float    rr_threshold;         /* PathIntegrator's rrThreshold (integrator.h:72, the reference's default is 1); read only under
+                                      RT_RENDER_LI; 0 switches Li's Russian roulette off (every path then runs to max_depth) */
 } rt_render_opts;
 
 enum {

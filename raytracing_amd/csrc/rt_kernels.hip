@@ -2367,8 +2367,6 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
         pool = std::min<size_t>((size_t)1 << 30, std::max<size_t>((size_t)1 << 20, free_b / 2 / 200));
     }
     int spb = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(S, 1), pool / npix));
-    size_t n_pass = npix * (size_t)spb;
-    if (n_pass >= (1ull << 31)) { set_error(ctx, "rt_render: pass too large"); return -1; }
     // queue segments = grid of every frame kernel: five blocks per CU where every kernel of the frame allows it
     const int ncu = std::max(1, ctx->n_cu);
     const bool small_tree = this_->dev.n_nodes <= 4096;
@@ -2376,18 +2374,33 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     const bool five_fit = !this_->classes[RT_MAT_METAL] && !this_->classes[RT_MAT_PLASTIC] && !this_->classes[RT_MAT_ROUGHGLASS];
     int nseg = env_int("RT_AMD_FRAME_BLOCKS_PER_CU", (small_tree || five_fit) ? 5 : 4) * ncu;
     nseg = std::max(RT_BLOCK, std::min(RT_SEG_BLOCKS, nseg / RT_BLOCK * RT_BLOCK));
-    // segment capacity: a block's share of the pass, plus room for the rounding of every class kernel's share
-    // (a block that takes chunks of RT_BLOCK round robin handles at most its even share rounded up to a chunk, once per class kernel)
-    size_t share = (n_pass + nseg - 1) / nseg;
-    share = (share + RT_BLOCK - 1) & ~(size_t)(RT_BLOCK - 1);
-    size_t segcap = share + (size_t)RT_BLOCK * (RT_NUM_CLASSES + 1);
-    size_t cap = segcap * nseg;
-    if (cap >= (1ull << 31)) { set_error(ctx, "rt_render: pass too large"); return -1; }
-    if (cap > this_->ws_cap) {
-        HIP_OK(this_->d_q[0].alloc(12 * cap * 4)); HIP_OK(this_->d_q[1].alloc(12 * cap * 4));
-        HIP_OK(this_->d_hits.alloc(5 * cap * 4)); HIP_OK(this_->d_cls.alloc((size_t)RT_NUM_CLASSES * cap * 4));
-        HIP_OK(this_->d_shadow.alloc(10 * cap * 4)); HIP_OK(this_->d_lbuf.alloc(cap * 16));
-        this_->ws_cap = cap;
+    size_t n_pass = 0, segcap = 0;
+    while (true) {
+        n_pass = npix * (size_t)spb;
+        if (n_pass >= (1ull << 31)) { set_error(ctx, "rt_render: pass too large"); return -1; }
+        // segment capacity: a block's share of the pass, plus room for the rounding of every class kernel's share
+        // (a block that takes chunks of RT_BLOCK round robin handles at most its even share rounded up to a chunk, once per class kernel)
+        size_t share = (n_pass + nseg - 1) / nseg;
+        share = (share + RT_BLOCK - 1) & ~(size_t)(RT_BLOCK - 1);
+        segcap = share + (size_t)RT_BLOCK * (RT_NUM_CLASSES + 1);
+        size_t cap = segcap * nseg;
+        if (cap >= (1ull << 31)) { set_error(ctx, "rt_render: pass too large"); return -1; }
+        if (cap <= this_->ws_cap) break;
+        hipError_t e = this_->d_q[0].alloc(12 * cap * 4);
+        if (e == hipSuccess) e = this_->d_q[1].alloc(12 * cap * 4);
+        if (e == hipSuccess) e = this_->d_hits.alloc(5 * cap * 4);
+        if (e == hipSuccess) e = this_->d_cls.alloc((size_t)RT_NUM_CLASSES * cap * 4);
+        if (e == hipSuccess) e = this_->d_shadow.alloc(10 * cap * 4);
+        if (e == hipSuccess) e = this_->d_lbuf.alloc(cap * 16);
+        if (e == hipSuccess) { this_->ws_cap = cap; break; }
+        // someone else took the memory between the query and the allocation (another context on this GPU): give everything back and
+        // try with passes of half the size; an explicit pool_paths that does not fit is the caller's error
+        (void)this_->d_q[0].alloc(0); (void)this_->d_q[1].alloc(0); (void)this_->d_hits.alloc(0); (void)this_->d_cls.alloc(0);
+        (void)this_->d_shadow.alloc(0); (void)this_->d_lbuf.alloc(0);
+        this_->ws_cap = 0;
+        (void)hipGetLastError();
+        if (e != hipErrorOutOfMemory || o->pool_paths > 0 || spb == 1) { set_error(ctx, std::string("rt_render: workspace allocation: ") + hipGetErrorString(e)); return -1; }
+        spb = (spb + 1) / 2;
     }
     size_t n_bounce = (size_t)o->max_depth + 2;
     size_t counts_bytes = n_bounce * sizeof(BounceCounts), stats_bytes = n_bounce * sizeof(BounceStats);
