@@ -1,5 +1,5 @@
 #!/bin/bash
-# Regenerates the round-2 profile summaries (copy them from gpurun_out/r02 to profiles/ afterwards).  Run on the GPU box from the repo root.
+# Regenerates the r02_* profile summaries (copy them from gpurun_out/r02 to profiles/ afterwards).  Run on the GPU box from the repo root.
 set -e
 R=$PWD
 OUT=$R/gpurun_out/r02
