@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1717,13 +1718,23 @@ struct rt_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr; // made once, so that the entry point that must not allocate can time its launches
 };
 static std::string g_init_error;
-static void set_error(rt_ctx *c, const std::string &s) { if (c) c->error = s; else g_init_error = s; }
+static std::mutex g_error_mutex;      // render lanes report errors from their own threads
+static void set_error(rt_ctx *c, const std::string &s) { std::lock_guard<std::mutex> g(g_error_mutex); if (c) c->error = s; else g_init_error = s; }
 
 struct DevBuf {
     void *p = nullptr; size_t bytes = 0;
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t b) { if (p) { (void)hipFree(p); p = nullptr; } bytes = b; return b ? hipMalloc(&p, b) : hipSuccess; }
     hipError_t ensure(size_t b) { if (b <= bytes && p) return hipSuccess; return alloc(b); }
+};
+
+#define RT_MAX_LANES 4
+struct RenderLane {
+    hipStream_t stream = nullptr;
+    DevBuf d_q[2], d_hits, d_cls, d_shadow, d_lbuf, d_counters, d_sum, d_spill_own;
+    int *spill = nullptr;            // traversal-stack spill area of this lane's launches (lane 0: the scene's own)
+    size_t ws_cap = 0, sum_pixels = 0;
+    std::vector<float> survival;     // fraction of a pass's paths still alive at each bounce, from the last pass that ran every bounce (k_finish)
 };
 
 struct rt_scene {
@@ -1734,12 +1745,16 @@ struct rt_scene {
     bool classes[RT_NUM_CLASSES] = {};
     DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_envs, d_light_cdf, d_spill, d_pairs, d_quads;
     int interior_depth = 0;
-    std::vector<float> survival;     // fraction of a pass's paths still alive at each bounce, from the last pass that ran every bounce (k_finish)
     std::vector<DevBuf *> d_texels;
-    // render workspace
-    DevBuf d_q[2], d_hits, d_cls, d_shadow, d_lbuf, d_counters, d_sum, d_trace_io, d_work;
-    size_t ws_cap = 0, sum_pixels = 0;
-    ~rt_scene() { for (DevBuf *b : d_texels) delete b; }
+    DevBuf d_trace_io, d_work;
+    size_t spill_bytes = 0;
+    // Rendering runs as up to RT_MAX_LANES independent wavefront pipelines ("lanes") at once, each on its own HIP stream with its own
+    // queues, over its own share of the samples (rt_render_device).  Lane 0 runs on the context's stream and owns the result buffer.
+    RenderLane lanes[RT_MAX_LANES];
+    ~rt_scene() {
+        for (DevBuf *b : d_texels) delete b;
+        for (int k = 1; k < RT_MAX_LANES; ++k) if (lanes[k].stream) (void)hipStreamDestroy(lanes[k].stream);
+    }
 };
 
 static rt_ctx *ctx_of(rt_ctx *c) { return c; }
@@ -2128,6 +2143,7 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     if (quads_ok) HIP_OK(up(sc->d_quads, quads.data(), quads.size() * 4));
     size_t spill_ints = (size_t)persistent_grid(ctx) * RT_BLOCK * (size_t)std::max(RT_MAX_STACK, quads_ok ? quad_cap : 0) * 2;
     HIP_OK(sc->d_spill.alloc(spill_ints * 4));
+    sc->spill_bytes = spill_ints * 4;
     DevScene &D = sc->dev;
     D.nodes = (const float4 *)sc->d_nodes.p; D.slots = (const float4 *)sc->d_slots.p; D.frames = (const float4 *)sc->d_frames.p;
     D.slot_uv = (const float *)sc->d_uv.p; D.spheres = (const float *)sc->d_spheres.p; D.slot_material = (const int *)sc->d_slot_mat.p;
@@ -2146,6 +2162,7 @@ void rt_scene_destroy(rt_scene *scene) {
     if (!scene) return;
     (void)hipSetDevice(scene->ctx->device);
     (void)hipStreamSynchronize(scene->ctx->stream);
+    for (int k = 1; k < RT_MAX_LANES; ++k) if (scene->lanes[k].stream) (void)hipStreamSynchronize(scene->lanes[k].stream);
     delete scene;
 }
 
@@ -2315,57 +2332,48 @@ static bool shade_tables_in_lds(const DevScene &d) {
            !env_int("RT_AMD_SHADE_GLOBAL_TABLES", 0);
 }
 template <int MAT>
-static void launch_shade(rt_scene *s, const RenderParams &rp, int bounce, const PathQueue &q, const PathQueue &qn, const HitBuf &hb, uint32_t cap,
+static void launch_shade(rt_scene *s, RenderLane &ln, const RenderParams &rp, int bounce, const PathQueue &q, const PathQueue &qn, const HitBuf &hb, uint32_t cap,
                          uint32_t segcap, const ShadowQueue &sq, int nseg, bool fuse_shadow, float4 *lbuf, BounceStats *stats) {
     if (rp.li || rp.nee_mode) {   // the estimators next to Li_re: one general variant (tables in global memory, either kind of light)
-        hipLaunchKernelGGL((k_shade<MAT, 0, false, true, true>), dim3(nseg), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
-                           cap, segcap, sq, (BounceCounts *)s->d_counters.p, lbuf, stats);
+        hipLaunchKernelGGL((k_shade<MAT, 0, false, true, true>), dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)ln.d_cls.p,
+                           cap, segcap, sq, (BounceCounts *)ln.d_counters.p, lbuf, stats);
         return;
     }
     if (s->dev.envs) {        // scenes with an infinite area light: tables in global memory, shadow rays through the shadow queue
-        hipLaunchKernelGGL((k_shade<MAT, 0, false, true>), dim3(nseg), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
-                           cap, segcap, sq, (BounceCounts *)s->d_counters.p, lbuf, stats);
+        hipLaunchKernelGGL((k_shade<MAT, 0, false, true>), dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)ln.d_cls.p,
+                           cap, segcap, sq, (BounceCounts *)ln.d_counters.p, lbuf, stats);
         return;
     }
     const bool lds_tables = shade_tables_in_lds(s->dev);
     const size_t dyn = lds_tables ? shade_lds_bytes(s->dev) : 0;
     if (lds_tables && fuse_shadow)
-        hipLaunchKernelGGL((k_shade<MAT, 1, true>), dim3(nseg), dim3(RT_BLOCK), dyn, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
-                           cap, segcap, sq, (BounceCounts *)s->d_counters.p, lbuf, stats);
+        hipLaunchKernelGGL((k_shade<MAT, 1, true>), dim3(nseg), dim3(RT_BLOCK), dyn, ln.stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)ln.d_cls.p,
+                           cap, segcap, sq, (BounceCounts *)ln.d_counters.p, lbuf, stats);
     else if (lds_tables)
-        hipLaunchKernelGGL((k_shade<MAT, 1, false>), dim3(nseg), dim3(RT_BLOCK), dyn, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
-                           cap, segcap, sq, (BounceCounts *)s->d_counters.p, lbuf, stats);
+        hipLaunchKernelGGL((k_shade<MAT, 1, false>), dim3(nseg), dim3(RT_BLOCK), dyn, ln.stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)ln.d_cls.p,
+                           cap, segcap, sq, (BounceCounts *)ln.d_counters.p, lbuf, stats);
     else if (small_tables_in_lds(s->dev))
-        hipLaunchKernelGGL((k_shade<MAT, 2, false>), dim3(nseg), dim3(RT_BLOCK), small_tables_lds_bytes(s->dev), s->ctx->stream, s->dev, rp, bounce, q, qn, hb,
-                           (const uint32_t *)s->d_cls.p, cap, segcap, sq, (BounceCounts *)s->d_counters.p, lbuf, stats);
+        hipLaunchKernelGGL((k_shade<MAT, 2, false>), dim3(nseg), dim3(RT_BLOCK), small_tables_lds_bytes(s->dev), ln.stream, s->dev, rp, bounce, q, qn, hb,
+                           (const uint32_t *)ln.d_cls.p, cap, segcap, sq, (BounceCounts *)ln.d_counters.p, lbuf, stats);
     else
-        hipLaunchKernelGGL((k_shade<MAT, 0, false>), dim3(nseg), dim3(RT_BLOCK), 0, s->ctx->stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)s->d_cls.p,
-                           cap, segcap, sq, (BounceCounts *)s->d_counters.p, lbuf, stats);
+        hipLaunchKernelGGL((k_shade<MAT, 0, false>), dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, s->dev, rp, bounce, q, qn, hb, (const uint32_t *)ln.d_cls.p,
+                           cap, segcap, sq, (BounceCounts *)ln.d_counters.p, lbuf, stats);
 }
 }  // extern "C++"
 
-int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts *o, void **out_device_sum, rt_render_stats *stats) {
-    if (!this_ || !cam || !o || !out_device_sum) return -1;
+}  // extern "C"
+__global__ __launch_bounds__(RT_BLOCK) void k_add_frames(float *__restrict__ sum, const float *__restrict__ other, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) sum[i] += other[i];
+}
+extern "C" {
+// One lane's share of a render call: samples [o->sample_begin, o->sample_end) of every pixel into ln.d_sum.  `pool` = path slots this lane may keep
+// in flight.  Runs on the calling thread; every launch goes to ln.stream.
+static int render_lane(rt_scene *this_, RenderLane &ln, const rt_camera *cam, const rt_render_opts *o, size_t pool, bool pool_is_callers, rt_render_stats *stats) {
     rt_ctx *ctx = this_->ctx;
     HIP_OK(hipSetDevice(ctx->device));
     int W = cam->width, H = cam->height;
-    if (W <= 0 || H <= 0 || o->strata_x <= 0 || o->strata_y <= 0 || o->sample_begin < 0 || o->sample_end < o->sample_begin || o->max_depth < 0 || o->max_depth > 65534) {
-        set_error(ctx, "rt_render: invalid camera or options"); return -1;
-    }
     size_t npix = (size_t)W * H;
-    if (npix > (1u << 30)) { set_error(ctx, "rt_render: image too large"); return -1; }
     int S = o->sample_end - o->sample_begin;
-    // Paths per pass.  Every pass ends in a tail of near-empty bounces whose cost is fixed, so passes should be few and large:
-    // 200 bytes of queue state per path (two queues of 48, hits 20, class lists 28, shadow queue 40, radiance slot 16); up to half of the
-    // free HBM goes to it (at most 2^30 paths), so that the 655 M paths of an 800 x 800, 1024 spp frame are ONE pass of 131 GB on a 288 GB
-    // card: measured 1572 Msamples/s with three passes, 1598 with two, 1622 with one.
-    size_t pool = (size_t)o->pool_paths;
-    if (o->pool_paths <= 0) {
-        size_t free_b = 0, total_b = 0;
-        HIP_OK(hipMemGetInfo(&free_b, &total_b));
-        free_b += this_->ws_cap * 200;                       // the workspace of an earlier call is reused
-        pool = std::min<size_t>((size_t)1 << 30, std::max<size_t>((size_t)1 << 20, free_b / 2 / 200));
-    }
     int spb = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(S, 1), pool / npix));
     // queue segments = grid of every frame kernel: five blocks per CU where every kernel of the frame allows it
     const int ncu = std::max(1, ctx->n_cu);
@@ -2385,38 +2393,38 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
         segcap = share + (size_t)RT_BLOCK * (RT_NUM_CLASSES + 1);
         size_t cap = segcap * nseg;
         if (cap >= (1ull << 31)) { set_error(ctx, "rt_render: pass too large"); return -1; }
-        if (cap <= this_->ws_cap) break;
-        hipError_t e = this_->d_q[0].alloc(12 * cap * 4);
-        if (e == hipSuccess) e = this_->d_q[1].alloc(12 * cap * 4);
-        if (e == hipSuccess) e = this_->d_hits.alloc(5 * cap * 4);
-        if (e == hipSuccess) e = this_->d_cls.alloc((size_t)RT_NUM_CLASSES * cap * 4);
-        if (e == hipSuccess) e = this_->d_shadow.alloc(10 * cap * 4);
-        if (e == hipSuccess) e = this_->d_lbuf.alloc(cap * 16);
-        if (e == hipSuccess) { this_->ws_cap = cap; break; }
+        if (cap <= ln.ws_cap) break;
+        hipError_t e = ln.d_q[0].alloc(12 * cap * 4);
+        if (e == hipSuccess) e = ln.d_q[1].alloc(12 * cap * 4);
+        if (e == hipSuccess) e = ln.d_hits.alloc(5 * cap * 4);
+        if (e == hipSuccess) e = ln.d_cls.alloc((size_t)RT_NUM_CLASSES * cap * 4);
+        if (e == hipSuccess) e = ln.d_shadow.alloc(10 * cap * 4);
+        if (e == hipSuccess) e = ln.d_lbuf.alloc(cap * 16);
+        if (e == hipSuccess) { ln.ws_cap = cap; break; }
         // someone else took the memory between the query and the allocation (another context on this GPU): give everything back and
         // try with passes of half the size; an explicit pool_paths that does not fit is the caller's error
-        (void)this_->d_q[0].alloc(0); (void)this_->d_q[1].alloc(0); (void)this_->d_hits.alloc(0); (void)this_->d_cls.alloc(0);
-        (void)this_->d_shadow.alloc(0); (void)this_->d_lbuf.alloc(0);
-        this_->ws_cap = 0;
+        (void)ln.d_q[0].alloc(0); (void)ln.d_q[1].alloc(0); (void)ln.d_hits.alloc(0); (void)ln.d_cls.alloc(0);
+        (void)ln.d_shadow.alloc(0); (void)ln.d_lbuf.alloc(0);
+        ln.ws_cap = 0;
         (void)hipGetLastError();
-        if (e != hipErrorOutOfMemory || o->pool_paths > 0 || spb == 1) { set_error(ctx, std::string("rt_render: workspace allocation: ") + hipGetErrorString(e)); return -1; }
+        if (e != hipErrorOutOfMemory || pool_is_callers || spb == 1) { set_error(ctx, std::string("rt_render: workspace allocation: ") + hipGetErrorString(e)); return -1; }
         spb = (spb + 1) / 2;
     }
     size_t n_bounce = (size_t)o->max_depth + 2;
     size_t counts_bytes = n_bounce * sizeof(BounceCounts), stats_bytes = n_bounce * sizeof(BounceStats);
-    HIP_OK(this_->d_counters.ensure(counts_bytes + stats_bytes));
-    bool fresh = this_->sum_pixels != npix || !(o->flags & RT_RENDER_ACCUMULATE);
-    if (this_->sum_pixels != npix) { HIP_OK(this_->d_sum.alloc(npix * 3 * 4)); this_->sum_pixels = npix; }
-    if (fresh) HIP_OK(hipMemsetAsync(this_->d_sum.p, 0, npix * 3 * 4, ctx->stream));
+    HIP_OK(ln.d_counters.ensure(counts_bytes + stats_bytes));
+    bool fresh = ln.sum_pixels != npix || !(o->flags & RT_RENDER_ACCUMULATE);
+    if (ln.sum_pixels != npix) { HIP_OK(ln.d_sum.alloc(npix * 3 * 4)); ln.sum_pixels = npix; }
+    if (fresh) HIP_OK(hipMemsetAsync(ln.d_sum.p, 0, npix * 3 * 4, ln.stream));
 
-    size_t wcap = this_->ws_cap;
-    PathQueue q[2]; bind_queue(q[0], this_->d_q[0].p, wcap); bind_queue(q[1], this_->d_q[1].p, wcap);
-    HitBuf hb; { float *f = (float *)this_->d_hits.p; hb.slot = (int *)f; hb.t = f + wcap; hb.b0 = f + 2 * wcap; hb.b1 = f + 3 * wcap; hb.b2 = f + 4 * wcap; }
-    ShadowQueue sq; { float *f = (float *)this_->d_shadow.p; sq.id = (uint32_t *)f; sq.ox = f + wcap; sq.oy = f + 2 * wcap; sq.oz = f + 3 * wcap; sq.dx = f + 4 * wcap;
+    size_t wcap = ln.ws_cap;
+    PathQueue q[2]; bind_queue(q[0], ln.d_q[0].p, wcap); bind_queue(q[1], ln.d_q[1].p, wcap);
+    HitBuf hb; { float *f = (float *)ln.d_hits.p; hb.slot = (int *)f; hb.t = f + wcap; hb.b0 = f + 2 * wcap; hb.b1 = f + 3 * wcap; hb.b2 = f + 4 * wcap; }
+    ShadowQueue sq; { float *f = (float *)ln.d_shadow.p; sq.id = (uint32_t *)f; sq.ox = f + wcap; sq.oy = f + 2 * wcap; sq.oz = f + 3 * wcap; sq.dx = f + 4 * wcap;
                       sq.dy = f + 5 * wcap; sq.dz = f + 6 * wcap; sq.cr = f + 7 * wcap; sq.cg = f + 8 * wcap; sq.cb = f + 9 * wcap; }
-    BounceCounts *counts = (BounceCounts *)this_->d_counters.p;
-    BounceStats *bstats = (BounceStats *)((char *)this_->d_counters.p + counts_bytes);
-    float4 *lbuf = (float4 *)this_->d_lbuf.p;
+    BounceCounts *counts = (BounceCounts *)ln.d_counters.p;
+    BounceStats *bstats = (BounceStats *)((char *)ln.d_counters.p + counts_bytes);
+    float4 *lbuf = (float4 *)ln.d_lbuf.p;
     int grid = persistent_grid(ctx);
     if (nseg * RT_BLOCK > grid * RT_BLOCK) { set_error(ctx, "rt_render: spill area smaller than the wavefront grid"); return -1; }
 
@@ -2434,8 +2442,8 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     rt_render_stats st; memset(&st, 0, sizeof(st));
     EventPair ev;
     HIP_OK(ev.create());
-    HIP_OK(hipEventRecord(ev.a, ctx->stream));
-    KernelTimer tm; tm.on = (o->flags & RT_RENDER_TIME_KERNELS) != 0; tm.stream = ctx->stream;
+    HIP_OK(hipEventRecord(ev.a, ln.stream));
+    KernelTimer tm; tm.on = (o->flags & RT_RENDER_TIME_KERNELS) != 0; tm.stream = ln.stream;
     std::vector<BounceStats> hs(n_bounce);
     const uint32_t ucap = (uint32_t)wcap, useg = (uint32_t)segcap;
     // scenes small enough are traversed out of an LDS copy (no spheres: their records stay in global memory)
@@ -2473,46 +2481,46 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     for (int s0 = o->sample_begin; s0 < o->sample_end; s0 += spb) {
         int cur = std::min(spb, o->sample_end - s0);
         rp.spb = cur; rp.d_spb = make_fastdiv((uint32_t)cur); rp.sample0 = s0; rp.n_paths = (uint32_t)(npix * (size_t)cur);
-        HIP_OK(hipMemsetAsync(bstats, 0, stats_bytes, ctx->stream));
+        HIP_OK(hipMemsetAsync(bstats, 0, stats_bytes, ln.stream));
         tm.begin_pass();
-        hipLaunchKernelGGL(k_raygen, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, rp, q[0], useg, lbuf, counts);
+        hipLaunchKernelGGL(k_raygen, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, rp, q[0], useg, lbuf, counts);
         tm.mark(RT_TIME_OTHER);
         int cq = 0;
         // k_finish takes over at the first bounce expected to hold no more than two chunks of 64 paths per wave of the grid
         int finish_at = 1 << 30;
         if (use_finish)
-            for (size_t b = (size_t)env_int("RT_AMD_FINISH_MIN_BOUNCE", 4); b < this_->survival.size(); ++b)
-                if ((double)this_->survival[b] * rp.n_paths <= (double)finish_chunks * RT_WAVE * (RT_BLOCK / RT_WAVE) * nseg) { finish_at = (int)b; break; }
+            for (size_t b = (size_t)env_int("RT_AMD_FINISH_MIN_BOUNCE", 4); b < ln.survival.size(); ++b)
+                if ((double)ln.survival[b] * rp.n_paths <= (double)finish_chunks * RT_WAVE * (RT_BLOCK / RT_WAVE) * nseg) { finish_at = (int)b; break; }
         for (int b = 0; b <= o->max_depth; ++b) {
             if (b >= finish_at) {
                 if (lds_scene)
-                    hipLaunchKernelGGL(k_finish<true>, dim3(nseg), dim3(RT_BLOCK), shade_lds_bytes(this_->dev), ctx->stream, this_->dev, rp, b, q[cq], useg, lbuf,
-                                       counts, bstats, (int *)this_->d_spill.p);
+                    hipLaunchKernelGGL(k_finish<true>, dim3(nseg), dim3(RT_BLOCK), shade_lds_bytes(this_->dev), ln.stream, this_->dev, rp, b, q[cq], useg, lbuf,
+                                       counts, bstats, ln.spill);
                 else
-                    hipLaunchKernelGGL(k_finish<false>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], useg, lbuf, counts, bstats,
-                                       (int *)this_->d_spill.p);
+                    hipLaunchKernelGGL(k_finish<false>, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, rp, b, q[cq], useg, lbuf, counts, bstats,
+                                       ln.spill);
                 tm.mark(RT_TIME_OTHER);
                 break;
             }
             if (frame_old || b < round_bounces) {
                 if (lds_scene && round_pairs && b >= carry_from)
-                    hipLaunchKernelGGL(k_extend_carry, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
+                    hipLaunchKernelGGL(k_extend_carry, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)ln.d_cls.p,
                                        ucap, useg, lbuf, counts, bstats);
                 else if (lds_scene)
-                    hipLaunchKernelGGL(k_extend<true>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
-                                       ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, round_pairs | rr_extend);
+                    hipLaunchKernelGGL(k_extend<true>, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)ln.d_cls.p,
+                                       ucap, useg, lbuf, counts, bstats, ln.spill, round_pairs | rr_extend);
                 else
-                    hipLaunchKernelGGL(k_extend<false>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)this_->d_cls.p,
-                                       ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p, round_quads | rr_extend);
+                    hipLaunchKernelGGL(k_extend<false>, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)ln.d_cls.p,
+                                       ucap, useg, lbuf, counts, bstats, ln.spill, round_quads | rr_extend);
             } else if (walk_mode == RT_WALK_QUADS)
-                hipLaunchKernelGGL(k_extend_pl<RT_WALK_QUADS>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
-                                   (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
+                hipLaunchKernelGGL(k_extend_pl<RT_WALK_QUADS>, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, rp, b, q[cq], hb,
+                                   (uint32_t *)ln.d_cls.p, ucap, useg, lbuf, counts, bstats, ln.spill);
             else
-                hipLaunchKernelGGL(k_extend_pl<RT_WALK_PAIRS>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, rp, b, q[cq], hb,
-                                   (uint32_t *)this_->d_cls.p, ucap, useg, lbuf, counts, bstats, (int *)this_->d_spill.p);
+                hipLaunchKernelGGL(k_extend_pl<RT_WALK_PAIRS>, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, rp, b, q[cq], hb,
+                                   (uint32_t *)ln.d_cls.p, ucap, useg, lbuf, counts, bstats, ln.spill);
             tm.mark(RT_TIME_TRACE);
             if (rp.li && this_->dev.envs) {
-                hipLaunchKernelGGL(k_env_escape, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, q[cq], hb, useg, lbuf, counts);
+                hipLaunchKernelGGL(k_env_escape, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, b, q[cq], hb, useg, lbuf, counts);
                 tm.mark(RT_TIME_OTHER);
             }
             // UniformSampleAllLights: one shading launch (direct light of that light only) and one shadow launch per light, then the BSDF sampling
@@ -2520,33 +2528,33 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
             for (int step = 0; step < n_steps; ++step) {
             if (all_lights) {
                 rp.nee_mode = step < this_->dev.n_lights ? 1 : 2; rp.nee_light = step;
-                if (step > 0) HIP_OK(hipMemsetAsync(counts[b].shadow, 0, sizeof(counts[b].shadow), ctx->stream));
+                if (step > 0) HIP_OK(hipMemsetAsync(counts[b].shadow, 0, sizeof(counts[b].shadow), ln.stream));
             }
             if (b < o->max_depth) {
-                if (this_->classes[RT_MAT_MATTE]) launch_shade<RT_MAT_MATTE>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
-                if (this_->classes[RT_MAT_MIRROR] && !rp.merge_mirror) launch_shade<RT_MAT_MIRROR>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
-                if (this_->classes[RT_MAT_GLASS]) launch_shade<RT_MAT_GLASS>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
-                if (this_->classes[RT_MAT_METAL]) launch_shade<RT_MAT_METAL>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
-                if (this_->classes[RT_MAT_PLASTIC]) launch_shade<RT_MAT_PLASTIC>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
-                if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
-                if (this_->classes[RT_MAT_ROUGHGLASS]) launch_shade<RT_MAT_ROUGHGLASS>(this_, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
+                if (this_->classes[RT_MAT_MATTE]) launch_shade<RT_MAT_MATTE>(this_, ln, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
+                if (this_->classes[RT_MAT_MIRROR] && !rp.merge_mirror) launch_shade<RT_MAT_MIRROR>(this_, ln, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
+                if (this_->classes[RT_MAT_GLASS]) launch_shade<RT_MAT_GLASS>(this_, ln, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
+                if (this_->classes[RT_MAT_METAL]) launch_shade<RT_MAT_METAL>(this_, ln, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
+                if (this_->classes[RT_MAT_PLASTIC]) launch_shade<RT_MAT_PLASTIC>(this_, ln, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
+                if (this_->classes[RT_MAT_METALROUGH]) launch_shade<RT_MAT_METALROUGH>(this_, ln, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
+                if (this_->classes[RT_MAT_ROUGHGLASS]) launch_shade<RT_MAT_ROUGHGLASS>(this_, ln, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
                 tm.mark(RT_TIME_SHADE);
                 if (this_->dev.n_lights > 0 && !fuse_shadow && rp.nee_mode != 2) {
                     if (frame_old || b < round_bounces || all_lights) {      // (k_shadow_pl borrows the hit buffer, which the next light's shading still reads)
                         if (b >= shadow_carry_from)
-                            hipLaunchKernelGGL(k_shadow_carry, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats);
+                            hipLaunchKernelGGL(k_shadow_carry, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, b, sq, useg, lbuf, counts, bstats);
                         else if (lds_scene)
-                            hipLaunchKernelGGL(k_shadow<true>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
-                                               (int *)this_->d_spill.p, round_pairs | rr_shadow);
+                            hipLaunchKernelGGL(k_shadow<true>, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
+                                               ln.spill, round_pairs | rr_shadow);
                         else
-                            hipLaunchKernelGGL(k_shadow<false>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
-                                               (int *)this_->d_spill.p, round_quads | rr_shadow);
+                            hipLaunchKernelGGL(k_shadow<false>, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
+                                               ln.spill, round_quads | rr_shadow);
                     } else if (walk_mode == RT_WALK_QUADS)       // the hit buffer's slot array is free once the shading kernels are done
-                        hipLaunchKernelGGL(k_shadow_pl<RT_WALK_QUADS>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, hb.slot, useg, lbuf,
-                                           counts, bstats, (int *)this_->d_spill.p);
+                        hipLaunchKernelGGL(k_shadow_pl<RT_WALK_QUADS>, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, b, sq, hb.slot, useg, lbuf,
+                                           counts, bstats, ln.spill);
                     else
-                        hipLaunchKernelGGL(k_shadow_pl<RT_WALK_PAIRS>, dim3(nseg), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, b, sq, hb.slot, useg, lbuf,
-                                           counts, bstats, (int *)this_->d_spill.p);
+                        hipLaunchKernelGGL(k_shadow_pl<RT_WALK_PAIRS>, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, b, sq, hb.slot, useg, lbuf,
+                                           counts, bstats, ln.spill);
                     tm.mark(RT_TIME_SHADOW);
                 }
             }
@@ -2555,24 +2563,24 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
         }
         if (cur >= 32) {
             int ag = (int)std::min<size_t>((npix + RT_BLOCK / RT_WAVE - 1) / (RT_BLOCK / RT_WAVE), (size_t)grid * 8);
-            hipLaunchKernelGGL(k_accumulate_wave, dim3(ag), dim3(RT_BLOCK), 0, ctx->stream, (const float4 *)lbuf, cur, (uint32_t)npix, (float *)this_->d_sum.p);
+            hipLaunchKernelGGL(k_accumulate_wave, dim3(ag), dim3(RT_BLOCK), 0, ln.stream, (const float4 *)lbuf, cur, (uint32_t)npix, (float *)ln.d_sum.p);
         } else {
             int ag = (int)std::min<size_t>((npix + RT_BLOCK - 1) / RT_BLOCK, (size_t)grid * 4);
-            hipLaunchKernelGGL(k_accumulate, dim3(ag), dim3(RT_BLOCK), 0, ctx->stream, (const float4 *)lbuf, cur, (uint32_t)npix, (float *)this_->d_sum.p);
+            hipLaunchKernelGGL(k_accumulate, dim3(ag), dim3(RT_BLOCK), 0, ln.stream, (const float4 *)lbuf, cur, (uint32_t)npix, (float *)ln.d_sum.p);
         }
         tm.mark(RT_TIME_OTHER);
         HIP_OK(hipGetLastError());
-        HIP_OK(hipMemcpyAsync(hs.data(), bstats, stats_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_OK(hipStreamSynchronize(ctx->stream));
+        HIP_OK(hipMemcpyAsync(hs.data(), bstats, stats_bytes, hipMemcpyDeviceToHost, ln.stream));
+        HIP_OK(hipStreamSynchronize(ln.stream));
         tm.end_pass();
         st.samples += rp.n_paths;
         for (size_t b = 0; b < n_bounce; ++b) { st.rays_closest += hs[b].n_queue; st.rays_shadow += hs[b].n_shadow; if (hs[b].n_queue) st.iterations++; }
         if (use_finish && finish_at == 1 << 30 && rp.n_paths >= 4096) {       // a pass through every bounce: note how fast the paths die out
-            this_->survival.assign((size_t)o->max_depth + 1, 0.f);
-            for (int b = 0; b <= o->max_depth; ++b) this_->survival[b] = (float)((double)hs[b].n_queue / rp.n_paths);
+            ln.survival.assign((size_t)o->max_depth + 1, 0.f);
+            for (int b = 0; b <= o->max_depth; ++b) ln.survival[b] = (float)((double)hs[b].n_queue / rp.n_paths);
         }
     }
-    HIP_OK(hipEventRecord(ev.b, ctx->stream));
+    HIP_OK(hipEventRecord(ev.b, ln.stream));
     HIP_OK(hipEventSynchronize(ev.b));
     float ms = 0.f;
     HIP_OK(hipEventElapsedTime(&ms, ev.a, ev.b));
@@ -2580,16 +2588,94 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     st.seconds_trace = tm.seconds[RT_TIME_TRACE]; st.seconds_shade = tm.seconds[RT_TIME_SHADE]; st.seconds_shadow = tm.seconds[RT_TIME_SHADOW];
     st.seconds_other = tm.seconds[RT_TIME_OTHER];
     if (stats) *stats = st;
-    *out_device_sum = this_->d_sum.p;
+    return 0;
+}
+
+int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts *o, void **out_device_sum, rt_render_stats *stats) {
+    if (!this_ || !cam || !o || !out_device_sum) return -1;
+    rt_ctx *ctx = this_->ctx;
+    HIP_OK(hipSetDevice(ctx->device));
+    int W = cam->width, H = cam->height;
+    if (W <= 0 || H <= 0 || o->strata_x <= 0 || o->strata_y <= 0 || o->sample_begin < 0 || o->sample_end < o->sample_begin || o->max_depth < 0 || o->max_depth > 65534) {
+        set_error(ctx, "rt_render: invalid camera or options"); return -1;
+    }
+    size_t npix = (size_t)W * H;
+    if (npix > (1u << 30)) { set_error(ctx, "rt_render: image too large"); return -1; }
+    const int S = o->sample_end - o->sample_begin;
+    // Lanes.  Two independent pipelines over half of the samples each finish a frame sooner than one pipeline over all of them: the
+    // kernels of one lane fill the other's tails (every bounce ends with a few blocks still running) and the memory waits of its
+    // shading kernels.  Measured on the 800 x 800, 1024 spp Cornell frame: 1608 Msamples/s with one lane, 1869 with two, 1891 with three,
+    // 1790 with four.  Small renders stay on one lane, and so does a call that asks for per-class kernel times (the events that
+    // bracket every launch would serialise the lanes).
+    int n_lanes = std::max(1, std::min(RT_MAX_LANES, env_int("RT_AMD_RENDER_LANES", 2)));
+    if ((o->flags & RT_RENDER_TIME_KERNELS) || npix * (size_t)std::max(S, 0) < ((size_t)16 << 20)) n_lanes = 1;
+    n_lanes = std::max(1, std::min(n_lanes, S));
+    // Paths per pass.  Every pass ends in a tail of near-empty bounces whose cost is fixed, so passes should be few and large:
+    // 200 bytes of queue state per path (two queues of 48, hits 20, class lists 28, shadow queue 40, radiance slot 16); up to half of the
+    // free HBM goes to it (at most 2^30 paths), shared out over the lanes, so that the 655 M paths of an 800 x 800, 1024 spp frame are ONE pass
+    // per lane on a 288 GB card: measured 1572 Msamples/s with three passes, 1598 with two, 1622 with one (one lane).
+    size_t pool = (size_t)o->pool_paths;
+    if (o->pool_paths <= 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_OK(hipMemGetInfo(&free_b, &total_b));
+        for (int k = 0; k < RT_MAX_LANES; ++k) free_b += this_->lanes[k].ws_cap * 200;       // the workspaces of an earlier call are reused
+        pool = std::min<size_t>((size_t)1 << 30, std::max<size_t>((size_t)1 << 20, free_b / 2 / 200));
+    }
+    pool = std::max<size_t>(1, pool / n_lanes);
+    for (int k = n_lanes; k < RT_MAX_LANES; ++k) {         // lanes this call does not use give their queues back
+        RenderLane &ln = this_->lanes[k];
+        if (ln.ws_cap) { (void)ln.d_q[0].alloc(0); (void)ln.d_q[1].alloc(0); (void)ln.d_hits.alloc(0); (void)ln.d_cls.alloc(0); (void)ln.d_shadow.alloc(0); (void)ln.d_lbuf.alloc(0); ln.ws_cap = 0; }
+    }
+    this_->lanes[0].stream = ctx->stream; this_->lanes[0].spill = (int *)this_->d_spill.p;
+    for (int k = 1; k < n_lanes; ++k) {
+        RenderLane &ln = this_->lanes[k];
+        if (!ln.stream) HIP_OK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        HIP_OK(ln.d_spill_own.ensure(this_->spill_bytes));
+        ln.spill = (int *)ln.d_spill_own.p;
+    }
+    EventPair ev;
+    HIP_OK(ev.create());
+    HIP_OK(hipEventRecord(ev.a, ctx->stream));
+    std::vector<rt_render_opts> lo((size_t)n_lanes, *o);
+    std::vector<rt_render_stats> ls((size_t)n_lanes);
+    std::vector<int> rc((size_t)n_lanes, 0);
+    for (int k = 0; k < n_lanes; ++k) {
+        int32_t b = 0, e = 0;
+        rt_split_samples(S, k, n_lanes, &b, &e);
+        lo[k].sample_begin = o->sample_begin + b; lo[k].sample_end = o->sample_begin + e;
+        if (k) lo[k].flags &= ~RT_RENDER_ACCUMULATE;       // only lane 0's buffer carries an earlier call's sums
+        memset(&ls[k], 0, sizeof(ls[k]));
+    }
+    {
+        std::vector<std::thread> th;
+        for (int k = 1; k < n_lanes; ++k)
+            th.emplace_back([&, k]() { rc[k] = render_lane(this_, this_->lanes[k], cam, &lo[k], pool, o->pool_paths > 0, &ls[k]); });
+        rc[0] = render_lane(this_, this_->lanes[0], cam, &lo[0], pool, o->pool_paths > 0, &ls[0]);
+        for (auto &t : th) t.join();
+    }
+    for (int k = 0; k < n_lanes; ++k) if (rc[k] != 0) return rc[k];
+    // every lane has synchronised its stream; the other lanes' sums are added to lane 0's in lane order, so the result does not depend on timing
+    for (int k = 1; k < n_lanes; ++k)
+        hipLaunchKernelGGL(k_add_frames, dim3(std::max(1, ctx->n_cu) * 4), dim3(RT_BLOCK), 0, ctx->stream, (float *)this_->lanes[0].d_sum.p,
+                           (const float *)this_->lanes[k].d_sum.p, npix * 3);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipEventRecord(ev.b, ctx->stream));
+    HIP_OK(hipEventSynchronize(ev.b));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, ev.a, ev.b));
+    rt_render_stats st = ls[0];
+    for (int k = 1; k < n_lanes; ++k) {
+        st.samples += ls[k].samples; st.rays_closest += ls[k].rays_closest; st.rays_shadow += ls[k].rays_shadow; st.iterations += ls[k].iterations;
+    }
+    st.seconds_total = (double)ms * 1e-3;
+    if (stats) *stats = st;
+    *out_device_sum = this_->lanes[0].d_sum.p;
     return 0;
 }
 
 // ---------------------------------------------------------------- several GPUs --
 }  // extern "C"
 
-__global__ __launch_bounds__(RT_BLOCK) void k_add_frames(float *__restrict__ sum, const float *__restrict__ other, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) sum[i] += other[i];
-}
 
 struct rt_multi {
     std::vector<rt_ctx *> ctx;

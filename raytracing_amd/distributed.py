@@ -18,7 +18,10 @@ def split_samples(total, rank, world):
 def reduce_frame(frame, dist, dst=0):
     """One collective per frame: sum of the per-rank radiance sums lands on rank `dst`."""
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM)
+        if getattr(frame, "is_cuda", False) and dist.get_backend() == "gloo":
+            dist.all_reduce(frame, op=dist.ReduceOp.SUM)      # gloo has no reduce for device tensors (one-GPU rehearsals only)
+        else:
+            dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM)
     return frame
 
 

@@ -390,6 +390,33 @@ def test_frame_walks_give_identical_images(name, w, device_scene, host_scene, mo
         assert np.array_equal(img, base), env
 
 
+@pytest.mark.parametrize("name,w,sx", [("cornell", 800, 6), ("helmet", 720, 6)])
+def test_render_lanes_share_the_samples(name, w, sx, device_scene, host_scene, monkeypatch):
+    """Renders of 16 Mi paths and more run as several lanes at once, each over its share of the samples on its own stream, and the lane
+    sums are added in lane order.  Every sample is a pure function of (pixel, sample), so 1, 2, 3 and 4 lanes trace exactly the same
+    rays and give the same image up to the order of the per-pixel additions; the default is two lanes; an accumulating second call adds
+    onto the first lane's buffer only once."""
+    ds = device_scene(name)
+    cam = host_scene(name).camera(w, w)
+    opts = ra.make_opts(sx, sx)
+    assert w * w * sx * sx >= 16 << 20
+    monkeypatch.setenv("RT_AMD_RENDER_LANES", "1")
+    base, st = ds.render(cam, opts)
+    for lanes in ("2", "3", "4", None):
+        if lanes is None:
+            monkeypatch.delenv("RT_AMD_RENDER_LANES")
+        else:
+            monkeypatch.setenv("RT_AMD_RENDER_LANES", lanes)
+        img, st2 = ds.render(cam, opts)
+        assert (st2.samples, st2.rays_closest, st2.rays_shadow) == (st.samples, st.rays_closest, st.rays_shadow), lanes
+        assert np.allclose(img, base, rtol=2e-5, atol=1e-6), (lanes, np.abs(img - base).max())
+    half = sx * sx // 2
+    a, _ = ds.render(cam, ra.make_opts(sx, sx, begin=0, end=half))
+    both, _ = ds.render(cam, ra.make_opts(sx, sx, begin=half, end=sx * sx, flags=capi.RT_RENDER_ACCUMULATE))
+    assert np.allclose(both, base, rtol=2e-5, atol=1e-6)
+    assert np.all(both.sum(axis=(0, 1)) > 1.5 * a.sum(axis=(0, 1)))
+
+
 def test_scene_create_rejects_inconsistent_descriptions(host_scene, gpu_ctx):
     """Indices and tree links are validated on the host before any kernel can follow them."""
     import ctypes as C
