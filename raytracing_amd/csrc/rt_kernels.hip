@@ -2605,7 +2605,8 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     // Lanes.  Two independent pipelines over half of the samples each finish a frame sooner than one pipeline over all of them: the
     // kernels of one lane fill the other's tails (every bounce ends with a few blocks still running) and the memory waits of its
     // shading kernels.  Measured on the 800 x 800, 1024 spp Cornell frame: 1608 Msamples/s with one lane, 1869 with two, 1891 with three,
-    // 1790 with four.  Small renders stay on one lane, and so does a call that asks for per-class kernel times (the events that
+    // 1790 with four; unequal shares (56 / 62 / 70 % to the first of two lanes, so that their tails would not coincide) are slower than equal
+    // ones.  Small renders stay on one lane, and so does a call that asks for per-class kernel times (the events that
     // bracket every launch would serialise the lanes).
     int n_lanes = std::max(1, std::min(RT_MAX_LANES, env_int("RT_AMD_RENDER_LANES", 2)));
     if ((o->flags & RT_RENDER_TIME_KERNELS) || npix * (size_t)std::max(S, 0) < ((size_t)16 << 20)) n_lanes = 1;
