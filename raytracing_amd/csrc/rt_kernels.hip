@@ -1734,6 +1734,7 @@ struct RenderLane {
     DevBuf d_q[2], d_hits, d_cls, d_shadow, d_lbuf, d_counters, d_sum, d_spill_own;
     int *spill = nullptr;            // traversal-stack spill area of this lane's launches (lane 0: the scene's own)
     size_t ws_cap = 0, sum_pixels = 0;
+    bool sum_valid = false;          // d_sum holds the sums of an earlier call (what RT_RENDER_ACCUMULATE adds to)
     std::vector<float> survival;     // fraction of a pass's paths still alive at each bounce, from the last pass that ran every bounce (k_finish)
 };
 
@@ -2366,9 +2367,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_add_frames(float *__restrict__ sum
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) sum[i] += other[i];
 }
 extern "C" {
-// One lane's share of a render call: samples [o->sample_begin, o->sample_end) of every pixel into ln.d_sum.  `pool` = path slots this lane may keep
-// in flight.  Runs on the calling thread; every launch goes to ln.stream.
-static int render_lane(rt_scene *this_, RenderLane &ln, const rt_camera *cam, const rt_render_opts *o, size_t pool, bool pool_is_callers, rt_render_stats *stats) {
+struct LanePlan { int spb = 1, nseg = RT_BLOCK; size_t segcap = 0; };
+// Pass size, queue segments and workspace of one lane (allocates; called before the render is timed).
+static int lane_prepare(rt_scene *this_, RenderLane &ln, const rt_camera *cam, const rt_render_opts *o, size_t pool, bool pool_is_callers, LanePlan &plan) {
     rt_ctx *ctx = this_->ctx;
     HIP_OK(hipSetDevice(ctx->device));
     int W = cam->width, H = cam->height;
@@ -2411,10 +2412,26 @@ static int render_lane(rt_scene *this_, RenderLane &ln, const rt_camera *cam, co
         spb = (spb + 1) / 2;
     }
     size_t n_bounce = (size_t)o->max_depth + 2;
+    HIP_OK(ln.d_counters.ensure(n_bounce * (sizeof(BounceCounts) + sizeof(BounceStats))));
+    if (ln.sum_pixels != npix) { HIP_OK(ln.d_sum.alloc(npix * 3 * 4)); ln.sum_pixels = npix; ln.sum_valid = false; }
+    plan.spb = spb; plan.nseg = nseg; plan.segcap = segcap;
+    return 0;
+}
+
+// One lane's share of a render call: samples [o->sample_begin, o->sample_end) of every pixel into ln.d_sum, with the plan lane_prepare made.
+// Runs on the calling thread; every launch goes to ln.stream.
+static int render_lane(rt_scene *this_, RenderLane &ln, const rt_camera *cam, const rt_render_opts *o, const LanePlan &plan, rt_render_stats *stats) {
+    rt_ctx *ctx = this_->ctx;
+    HIP_OK(hipSetDevice(ctx->device));
+    int W = cam->width, H = cam->height;
+    size_t npix = (size_t)W * H;
+    const int spb = plan.spb, nseg = plan.nseg;
+    const size_t segcap = plan.segcap;
+    const bool small_tree = this_->dev.n_nodes <= 4096;
+    size_t n_bounce = (size_t)o->max_depth + 2;
     size_t counts_bytes = n_bounce * sizeof(BounceCounts), stats_bytes = n_bounce * sizeof(BounceStats);
-    HIP_OK(ln.d_counters.ensure(counts_bytes + stats_bytes));
-    bool fresh = ln.sum_pixels != npix || !(o->flags & RT_RENDER_ACCUMULATE);
-    if (ln.sum_pixels != npix) { HIP_OK(ln.d_sum.alloc(npix * 3 * 4)); ln.sum_pixels = npix; }
+    bool fresh = !ln.sum_valid || !(o->flags & RT_RENDER_ACCUMULATE);
+    ln.sum_valid = true;
     if (fresh) HIP_OK(hipMemsetAsync(ln.d_sum.p, 0, npix * 3 * 4, ln.stream));
 
     size_t wcap = ln.ws_cap;
@@ -2634,9 +2651,6 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
         HIP_OK(ln.d_spill_own.ensure(this_->spill_bytes));
         ln.spill = (int *)ln.d_spill_own.p;
     }
-    EventPair ev;
-    HIP_OK(ev.create());
-    HIP_OK(hipEventRecord(ev.a, ctx->stream));
     std::vector<rt_render_opts> lo((size_t)n_lanes, *o);
     std::vector<rt_render_stats> ls((size_t)n_lanes);
     std::vector<int> rc((size_t)n_lanes, 0);
@@ -2647,11 +2661,19 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
         if (k) lo[k].flags &= ~RT_RENDER_ACCUMULATE;       // only lane 0's buffer carries an earlier call's sums
         memset(&ls[k], 0, sizeof(ls[k]));
     }
+    std::vector<LanePlan> plan((size_t)n_lanes);
+    for (int k = 0; k < n_lanes; ++k) {
+        int r = lane_prepare(this_, this_->lanes[k], cam, &lo[k], pool, o->pool_paths > 0, plan[k]);
+        if (r != 0) return r;
+    }
+    EventPair ev;
+    HIP_OK(ev.create());
+    HIP_OK(hipEventRecord(ev.a, ctx->stream));
     {
         std::vector<std::thread> th;
         for (int k = 1; k < n_lanes; ++k)
-            th.emplace_back([&, k]() { rc[k] = render_lane(this_, this_->lanes[k], cam, &lo[k], pool, o->pool_paths > 0, &ls[k]); });
-        rc[0] = render_lane(this_, this_->lanes[0], cam, &lo[0], pool, o->pool_paths > 0, &ls[0]);
+            th.emplace_back([&, k]() { rc[k] = render_lane(this_, this_->lanes[k], cam, &lo[k], plan[k], &ls[k]); });
+        rc[0] = render_lane(this_, this_->lanes[0], cam, &lo[0], plan[0], &ls[0]);
         for (auto &t : th) t.join();
     }
     for (int k = 0; k < n_lanes; ++k) if (rc[k] != 0) return rc[k];
