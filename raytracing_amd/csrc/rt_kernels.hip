@@ -1121,7 +1121,8 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
         if (FUSE && M != RT_MAT_MIRROR) {            // bvh.cpp:284-320 on the spot; tMax = 1 - ShadowEpsilon (interaction.h:27-32)
             // (Packing the block's shadow rays into full waves before the walk — about six paths in ten have one — was measured: through
             // the idle stack area of LDS, three barriers per chunk, walkers rotated over the waves: 4 % slower than each wave walking
-            // the rays of its own 64 paths, because the waves of a block then move in lockstep.)
+            // the rays of its own 64 paths, because the waves of a block then move in lockstep; with a second render lane filling the gaps it is
+            // still 5 % slower.)
             n_shadow_rays += (uint32_t)__popcll(__ballot(has_shadow));
             bool lit = false;
             if (has_shadow) {
