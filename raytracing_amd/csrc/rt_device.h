@@ -215,6 +215,17 @@ __device__ __forceinline__ RayShear ray_shear(F3 dir) {
     r.Sx = -dx / dz; r.Sy = -dy / dz; r.Sz = 1.f / dz;
     return r;
 }
+// The same with the ray's reciprocal direction at hand: Sz = 1 / d[kz] is that component of it, bit for bit (one IEEE division fewer per ray).
+__device__ __forceinline__ RayShear ray_shear(F3 dir, F3 invDir) {
+    float ax = fabsf(dir.x), ay = fabsf(dir.y), az = fabsf(dir.z);
+    RayShear r;
+    r.kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+    int kx = r.kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    float dx = pick3(dir, kx), dy = pick3(dir, ky), dz = pick3(dir, r.kz);
+    r.Sx = -dx / dz; r.Sy = -dy / dz; r.Sz = pick3(invDir, r.kz);
+    return r;
+}
 __device__ __forceinline__ bool triangle_test_sheared(F3 p0, F3 p1, F3 p2, F3 o, const RayShear &sh, float rayTMax, float &t, float &b0, float &b1, float &b2) {
     F3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
     int kz = sh.kz;

@@ -161,7 +161,7 @@ __device__ __forceinline__ bool lane_begin(const DevScene &sc, LaneTrav &L, Stac
     L.plain = finite_nonzero(L.invDir.x) && finite_nonzero(L.invDir.y) && finite_nonzero(L.invDir.z) && fabsf(o.x) < RT_INF && fabsf(o.y) < RT_INF &&
               fabsf(o.z) < RT_INF;
     L.hitSlot = -1; L.b0 = L.b1 = L.b2 = 0.f; L.found = false;
-    L.shear = ray_shear(d);
+    L.shear = ray_shear(d, L.invDir);
     st.reset();
     bool have = false;
     if (sc.n_nodes != 0) {
