@@ -2626,8 +2626,11 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     // 1790 with four; unequal shares (56 / 62 / 70 % to the first of two lanes, so that their tails would not coincide) are slower than equal
     // ones.  Small renders stay on one lane, and so does a call that asks for per-class kernel times (the events that
     // bracket every launch would serialise the lanes).
-    int n_lanes = std::max(1, std::min(RT_MAX_LANES, env_int("RT_AMD_RENDER_LANES", 2)));
-    if ((o->flags & RT_RENDER_TIME_KERNELS) || npix * (size_t)std::max(S, 0) < ((size_t)16 << 20)) n_lanes = 1;
+    // (a third lane pays once a call brings half a billion paths: 1881 -> 1896 on that frame, helmet 1440 x 1440 @ 1024 spp 611 -> 629; on the
+    // 128-spp share that one of eight ranks renders two lanes take 48.0 ms and three 49.2)
+    const size_t paths_total = npix * (size_t)std::max(S, 0);
+    int n_lanes = std::max(1, std::min(RT_MAX_LANES, env_int("RT_AMD_RENDER_LANES", paths_total >= ((size_t)512 << 20) ? 3 : 2)));
+    if ((o->flags & RT_RENDER_TIME_KERNELS) || paths_total < ((size_t)16 << 20)) n_lanes = 1;
     n_lanes = std::max(1, std::min(n_lanes, S));
     // Paths per pass.  Every pass ends in a tail of near-empty bounces whose cost is fixed, so passes should be few and large:
     // 200 bytes of queue state per path (two queues of 48, hits 20, class lists 28, shadow queue 40, radiance slot 16); up to half of the
