@@ -1428,12 +1428,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_carry(DevScene sc, int boun
         for (int k = 0; k < rounds; ++k) {
             while (L.mode == RT_LANE_WALK) {
                 uint32_t info; bool hv;
-                if (L.plain) lane_walk<false, true, RT_LDS_SCENE_NODES / 2>(s_nodes, L, pst, dummy, info, hv);
-                else lane_walk<false, false, RT_LDS_SCENE_NODES / 2>(s_nodes, L, pst, dummy, info, hv);
+                if (L.plain) lane_walk<false, true, RT_LDS_SCENE_NODES / 2, true>(s_nodes, L, pst, dummy, info, hv);
+                else lane_walk<false, false, RT_LDS_SCENE_NODES / 2, true>(s_nodes, L, pst, dummy, info, hv);
                 lane_enter(sc, L, info, hv);
             }
             if (L.mode == RT_LANE_LEAF) {
-                LeafOut r = lane_leaf<true, false>(sc, s_slots, L, pst, dummy);
+                LeafOut r = lane_leaf<true, false, true>(sc, s_slots, L, pst, dummy);
                 L.found = r.found;
                 lane_enter(sc, L, r.info, r.have);
             }
@@ -1495,16 +1495,16 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
         uint32_t info = 0; bool have = false, moved = false;
         if (nW >= nL && nW >= nI) {
             if (MODE == RT_WALK_QUADS) {
-                if (__ballot(walk && !L.plain) == 0) { if (walk) lane_walk_quad<true>(recs, L, st, info, have); }     // the whole wave takes one version
-                else if (walk) lane_walk_quad<false>(recs, L, st, info, have);
+                if (__ballot(walk && !L.plain) == 0) { if (walk) lane_walk_quad<true, ANY>(recs, L, st, info, have); }     // the whole wave takes one version
+                else if (walk) lane_walk_quad<false, ANY>(recs, L, st, info, have);
             } else {
-                if (__ballot(walk && !L.plain) == 0) { if (walk) lane_walk<false, true>(recs, L, st, dummy, info, have); }
-                else if (walk) lane_walk<false, false>(recs, L, st, dummy, info, have);
+                if (__ballot(walk && !L.plain) == 0) { if (walk) lane_walk<false, true, 1, ANY>(recs, L, st, dummy, info, have); }
+                else if (walk) lane_walk<false, false, 1, ANY>(recs, L, st, dummy, info, have);
             }
             moved = walk;
         } else if (nL >= nI) {
             if (leaf) {
-                LeafOut r = lane_leaf<ANY, false>(sc, slots, L, st, dummy);
+                LeafOut r = lane_leaf<ANY, false, ANY>(sc, slots, L, st, dummy);
                 L.found = r.found; L.tmax = r.tmax; L.hitSlot = r.hitSlot; L.b0 = r.b0; L.b1 = r.b1; L.b2 = r.b2;
                 info = r.info; have = r.have;
             }

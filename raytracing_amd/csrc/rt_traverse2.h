@@ -176,7 +176,9 @@ __device__ __forceinline__ bool lane_begin(const DevScene &sc, LaneTrav &L, Stac
 // the ray is finished).
 // KSTRIDE = 1: records stored one after the other (4 float4 each).  KSTRIDE = n: the k-th float4 of record r is at
 // pairs[k * n + r] — the layout of the LDS copy, where consecutive records then fall into different banks.
-template <bool COUNT, bool PLAIN, int KSTRIDE = 1, class Stack>
+// FIXED_TMAX: the ray's tMax never changes (any-hit rays: the first accepted primitive ends the walk), so the far child's test against
+// it is final now: a child that fails is not pushed, and a popped entry needs no second look.
+template <bool COUNT, bool PLAIN, int KSTRIDE = 1, bool FIXED_TMAX = false, class Stack>
 __device__ __forceinline__ void lane_walk(const float4 *pairs, const LaneTrav &L, Stack &st, uint32_t &nNodes, uint32_t &info, bool &have) {
     const float4 *P = pairs + (KSTRIDE == 1 ? 4 : 1) * (size_t)L.cur;
     float4 q0 = P[0], q1 = P[KSTRIDE], q2 = P[2 * KSTRIDE], q3 = P[3 * KSTRIDE];
@@ -204,10 +206,13 @@ __device__ __forceinline__ void lane_walk(const float4 *pairs, const LaneTrav &L
     // reference accepts  tScaled <= tMax * det  and then stores the rounded  tScaled / det ), so "fails now" does not imply
     // "fails later".  If the near child is rejected the far child is what the reference pops next, at the same tMax.
     bool nearNow = okN && tN < L.tmax, farNow = okF && tF < L.tmax;
-    if (nearNow && okF) st.push((int)infoF, tF);
+    if (nearNow && (FIXED_TMAX ? farNow : okF)) st.push((int)infoF, tF);
     info = nearNow ? infoN : infoF;
     have = nearNow || farNow;
-    if (!have) have = stack_next(L, st, info);
+    if (!have) {
+        if (FIXED_TMAX) { have = st.sp > 0; info = 0; if (have) { int i; float t; st.pop(i, t); info = (uint32_t)i; } }
+        else have = stack_next(L, st, info);
+    }
 }
 
 // ---- quad nodes ----
@@ -255,7 +260,7 @@ __device__ __forceinline__ void quad_side(const LaneTrav &L, float a0, float a1,
 }
 
 // One interior step over quad node L.cur: the node's two children and four grandchildren.
-template <bool PLAIN, class Stack>
+template <bool PLAIN, bool FIXED_TMAX = false, class Stack>
 __device__ __forceinline__ void lane_walk_quad(const float4 *quads, const LaneTrav &L, Stack &st, uint32_t &info, bool &have) {
     const float4 *Q = quads + 8 * (size_t)L.cur;
     float4 q0 = Q[0], q1 = Q[1], q2 = Q[2], q3 = Q[3], q4 = Q[4], q5 = Q[5], q6 = Q[6];
@@ -273,17 +278,21 @@ __device__ __forceinline__ void lane_walk_quad(const float4 *quads, const LaneTr
     // it by an ulp), so they are pushed on their tMax-independent part alone.
     QuadCand c0 = neg ? r0 : l0, c1 = neg ? r1 : l1, c2 = neg ? l0 : r0, c3 = neg ? l1 : r1;
     int first = c0.now ? 0 : (c1.now ? 1 : (c2.now ? 2 : (c3.now ? 3 : 4)));
-    if (c3.indep && first < 3) st.push((int)c3.info, c3.t);
-    if (c2.indep && first < 2) st.push((int)c2.info, c2.t);
-    if (c1.indep && first < 1) st.push((int)c1.info, c1.t);
+    // (FIXED_TMAX, as in lane_walk: a candidate's test against the ray's unchanging tMax is final, so only those that pass are pushed)
+    if ((FIXED_TMAX ? c3.now : c3.indep) && first < 3) st.push((int)c3.info, c3.t);
+    if ((FIXED_TMAX ? c2.now : c2.indep) && first < 2) st.push((int)c2.info, c2.t);
+    if ((FIXED_TMAX ? c1.now : c1.indep) && first < 1) st.push((int)c1.info, c1.t);
     info = first == 0 ? c0.info : (first == 1 ? c1.info : (first == 2 ? c2.info : c3.info));
     have = first < 4;
-    if (!have) have = stack_next(L, st, info);
+    if (!have) {
+        if (FIXED_TMAX) { have = st.sp > 0; info = 0; if (have) { int i; float t; st.pop(i, t); info = (uint32_t)i; } }
+        else have = stack_next(L, st, info);
+    }
 }
 
 // Test the primitives of the pending leaf (bvh.cpp:258-261 / 294-299) and pick the next node.
 struct LeafOut { bool found; float tmax; int hitSlot; float b0, b1, b2; uint32_t info; bool have; };
-template <bool ANY, bool COUNT, class Stack>
+template <bool ANY, bool COUNT, bool FIXED_POP = false, class Stack>
 __device__ __forceinline__ LeafOut lane_leaf(const DevScene &sc, const float4 *slots, const LaneTrav &L, Stack &st, uint32_t &nTests) {
     LeafOut r; r.found = L.found; r.tmax = L.tmax; r.hitSlot = L.hitSlot; r.b0 = L.b0; r.b1 = L.b1; r.b2 = L.b2;
     bool stop = false;
@@ -306,7 +315,9 @@ __device__ __forceinline__ LeafOut lane_leaf(const DevScene &sc, const float4 *s
         }
     }
     r.info = 0; r.have = false;
-    if (!stop) {          // stack entries are compared with the shrunken tMax
+    if (!stop && ANY && FIXED_POP) {      // every entry passed its test against the (fixed) tMax when it was pushed
+        if (st.sp > 0) { int i; float t; st.pop(i, t); r.info = (uint32_t)i; r.have = true; }
+    } else if (!stop) {          // stack entries are compared with the shrunken tMax
         while (!r.have && st.sp > 0) {
             int i; float t;
             st.pop(i, t);
@@ -329,14 +340,14 @@ __device__ __forceinline__ void trace_one(const DevScene &sc, const float4 *pair
         while (L.mode == RT_LANE_WALK) {
             uint32_t info; bool hv;
             if (QUADS) {
-                if (L.plain) lane_walk_quad<true>(pairs, L, st, info, hv);
-                else lane_walk_quad<false>(pairs, L, st, info, hv);
-            } else if (L.plain) lane_walk<false, true, KSTRIDE>(pairs, L, st, dummy, info, hv);
-            else lane_walk<false, false, KSTRIDE>(pairs, L, st, dummy, info, hv);
+                if (L.plain) lane_walk_quad<true, ANY>(pairs, L, st, info, hv);
+                else lane_walk_quad<false, ANY>(pairs, L, st, info, hv);
+            } else if (L.plain) lane_walk<false, true, KSTRIDE, ANY>(pairs, L, st, dummy, info, hv);
+            else lane_walk<false, false, KSTRIDE, ANY>(pairs, L, st, dummy, info, hv);
             lane_enter(sc, L, info, hv);
         }
         if (L.mode == RT_LANE_LEAF) {
-            LeafOut r = lane_leaf<ANY, false>(sc, slots, L, st, dummy);
+            LeafOut r = lane_leaf<ANY, false, ANY>(sc, slots, L, st, dummy);
             L.found = r.found; L.tmax = r.tmax; L.hitSlot = r.hitSlot; L.b0 = r.b0; L.b1 = r.b1; L.b2 = r.b2;
             lane_enter(sc, L, r.info, r.have);
         }
