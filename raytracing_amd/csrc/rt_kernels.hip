@@ -77,6 +77,7 @@ struct RenderParams {
     uint32_t n_paths;
     int rr_shade;       // shading kernels take their chunks round robin (block_chunks)
     FastDiv d_spb, d_width, d_strata_x, d_nstrata;      // divisions by spb, width, strata_x, strata_x * strata_y
+    int pack_shadow;    // fused shading kernels: a wave collects its shadow rays and walks them 64 at a time (k_shade)
     int merge_mirror;   // 2: k_shade<RT_MAT_MATTE> shades the mirror list in a second loop of the same launch; 1: mirror paths are binned with the
                         // matte ones and shaded by a branch of the matte code; 0: a launch of their own
     // The estimators next to Li_re (only the kernels built with GEN read these, and the emission step of the extend kernels reads li):
@@ -1095,7 +1096,20 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
     const uint32_t total = segment_prefix(bc->cls[M], s_prefix, s_wave);
     const ChunkLoop cl = block_chunks(total, rp.rr_shade);
     uint32_t seg = cl.start < cl.end ? segment_of(s_prefix, cl.start) : 0;
-    for (uint32_t base = cl.start; base < cl.end; base += cl.stride) {
+    // Shadow-ray packing (FUSE, rp.pack_shadow): about six paths in ten produce a shadow ray, so a wave that walks the rays of its own 64
+    // paths at once starts every walk with four lanes in ten idle.  Instead the wave parks its shadow rays (origin, direction, radiance,
+    // path id: ten words) in its own columns of the stack area, which is idle between walks, and walks them when 64 have come
+    // together; the rays that do not fit stay in their lanes' registers during the walk and are parked after it.  No barrier is
+    // involved: only the wave itself touches its columns.  One more trip through the loop, with no path in it, walks what is left.
+    // An any-hit answer does not depend on the lane that computes it and a path has one shadow ray per bounce, so the image is the same
+    // to the last bit.
+    constexpr bool WALKS = FUSE && M != RT_MAT_MIRROR;
+    const bool pack = WALKS && rp.pack_shadow != 0;
+    const uint32_t wave_col = threadIdx.x & ~(uint32_t)(RT_WAVE - 1), lane = threadIdx.x & (RT_WAVE - 1);
+    uint32_t n_parked = 0;
+    for (uint32_t base = cl.start; ; base += cl.stride) {
+        const bool flush = base >= cl.end;
+        if (flush && (!pack || n_parked == 0)) break;
         uint32_t j = base + threadIdx.x;
         bool active = j < cl.end;
         bool has_shadow = false, has_next = false;
@@ -1118,35 +1132,78 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
             has_shadow = out.has_shadow; has_next = out.has_next; nstate = out.nstate;
             so = out.so; sd = out.sd; sc3 = out.sc3; no = out.no; nd = out.nd; nT = out.nT;
         }
-        if (FUSE && M != RT_MAT_MIRROR) {            // bvh.cpp:284-320 on the spot; tMax = 1 - ShadowEpsilon (interaction.h:27-32)
-            // (Packing the block's shadow rays into full waves before the walk — about six paths in ten have one — was measured: through
-            // the idle stack area of LDS, three barriers per chunk, walkers rotated over the waves: 4 % slower than each wave walking
-            // the rays of its own 64 paths, because the waves of a block then move in lockstep; with a second render lane filling the gaps it is
-            // still 5 % slower.)
-            n_shadow_rays += (uint32_t)__popcll(__ballot(has_shadow));
-            bool lit = false;
-            if (has_shadow) {
-                LaneTrav L = {};
-                trace_one<true, RT_LDS_SCENE_NODES / 2>(sc_in, s_pairs, s_slots, so, sd, 1.f - 0.0001f, pst, L);
-                lit = !L.found;
+        // the next ray goes out first, so that its registers are free during the shadow walk
+        if (!flush) {
+            uint32_t npos = seg_base + block_append(has_next, &s_out[1]);
+            if (has_next) {
+                qn.ox[npos] = no.x; qn.oy[npos] = no.y; qn.oz[npos] = no.z; qn.dx[npos] = nd.x; qn.dy[npos] = nd.y; qn.dz[npos] = nd.z;
+                qn.tr[npos] = nT.x; qn.tg[npos] = nT.y; qn.tb[npos] = nT.z; qn.id[npos] = id; qn.state[npos] = nstate;
+                if (GEN && rp.li) qn.es[npos] = nes;
             }
-            if (lit) {
-                float4 Lr = lbuf[id];
-                Lr.x += sc3.x; Lr.y += sc3.y; Lr.z += sc3.z;
-                lbuf[id] = Lr;
+        }
+        if (WALKS) {            // bvh.cpp:284-320 on the spot; tMax = 1 - ShadowEpsilon (interaction.h:27-32)
+            // (Packing the BLOCK's shadow rays into full waves — three barriers per chunk, walkers rotated over the waves — was measured
+            // 4 % slower than no packing, because the waves of a block then move in lockstep.)
+            const uint64_t hm = __ballot(has_shadow);
+            const uint32_t nn = (uint32_t)__popcll(hm);
+            n_shadow_rays += nn;
+            bool walker = has_shadow;                    // this lane holds a ray to walk now (so, sd, sc3, id)
+            uint32_t rank = 0, room = 0;
+            bool walk_now = true;
+            if (pack) {
+                rank = prefix_in_mask(hm); room = RT_WAVE - n_parked;
+                walk_now = n_parked + nn >= RT_WAVE || flush;
+                int *col = &s_stack[wave_col];
+                if (has_shadow && rank < room) {         // park (column n_parked + rank)
+                    int *p = col + n_parked + rank;
+                    p[0] = __float_as_int(so.x); p[RT_BLOCK] = __float_as_int(so.y); p[2 * RT_BLOCK] = __float_as_int(so.z);
+                    p[3 * RT_BLOCK] = __float_as_int(sd.x); p[4 * RT_BLOCK] = __float_as_int(sd.y); p[5 * RT_BLOCK] = __float_as_int(sd.z);
+                    p[6 * RT_BLOCK] = __float_as_int(sc3.x); p[7 * RT_BLOCK] = __float_as_int(sc3.y); p[8 * RT_BLOCK] = __float_as_int(sc3.z);
+                    p[9 * RT_BLOCK] = (int)id;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+            if (walk_now) {
+                F3 wo_ = so, wd_ = sd, wc_ = sc3; uint32_t wid = id;
+                if (pack) {
+                    const uint32_t have = n_parked + nn < RT_WAVE ? n_parked + nn : RT_WAVE;
+                    const int *p = &s_stack[threadIdx.x];
+                    walker = lane < have;
+                    wo_ = f3(__int_as_float(p[0]), __int_as_float(p[RT_BLOCK]), __int_as_float(p[2 * RT_BLOCK]));
+                    wd_ = f3(__int_as_float(p[3 * RT_BLOCK]), __int_as_float(p[4 * RT_BLOCK]), __int_as_float(p[5 * RT_BLOCK]));
+                    wc_ = f3(__int_as_float(p[6 * RT_BLOCK]), __int_as_float(p[7 * RT_BLOCK]), __int_as_float(p[8 * RT_BLOCK]));
+                    wid = (uint32_t)p[9 * RT_BLOCK];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                bool lit = false;
+                if (walker) {
+                    LaneTrav L = {};
+                    trace_one<true, RT_LDS_SCENE_NODES / 2>(sc_in, s_pairs, s_slots, wo_, wd_, 1.f - 0.0001f, pst, L);
+                    lit = !L.found;
+                }
+                if (lit) {
+                    float4 Lr = lbuf[wid];
+                    Lr.x += wc_.x; Lr.y += wc_.y; Lr.z += wc_.z;
+                    lbuf[wid] = Lr;
+                }
+                if (pack) {                              // the rays that did not fit are parked now, from column 0
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (has_shadow && rank >= room) {
+                        int *p = &s_stack[wave_col] + (rank - room);
+                        p[0] = __float_as_int(so.x); p[RT_BLOCK] = __float_as_int(so.y); p[2 * RT_BLOCK] = __float_as_int(so.z);
+                        p[3 * RT_BLOCK] = __float_as_int(sd.x); p[4 * RT_BLOCK] = __float_as_int(sd.y); p[5 * RT_BLOCK] = __float_as_int(sd.z);
+                        p[6 * RT_BLOCK] = __float_as_int(sc3.x); p[7 * RT_BLOCK] = __float_as_int(sc3.y); p[8 * RT_BLOCK] = __float_as_int(sc3.z);
+                        p[9 * RT_BLOCK] = (int)id;
+                    }
+                    n_parked = n_parked + nn >= RT_WAVE ? n_parked + nn - RT_WAVE : 0;
+                }
+            } else n_parked += nn;
         } else if (M != RT_MAT_MIRROR) {
             uint32_t spos = seg_base + block_append(has_shadow, &s_out[0]);
             if (has_shadow) {
                 sq.id[spos] = id; sq.ox[spos] = so.x; sq.oy[spos] = so.y; sq.oz[spos] = so.z; sq.dx[spos] = sd.x; sq.dy[spos] = sd.y; sq.dz[spos] = sd.z;
                 sq.cr[spos] = sc3.x; sq.cg[spos] = sc3.y; sq.cb[spos] = sc3.z;
             }
-        }
-        uint32_t npos = seg_base + block_append(has_next, &s_out[1]);
-        if (has_next) {
-            qn.ox[npos] = no.x; qn.oy[npos] = no.y; qn.oz[npos] = no.z; qn.dx[npos] = nd.x; qn.dy[npos] = nd.y; qn.dz[npos] = nd.z;
-            qn.tr[npos] = nT.x; qn.tg[npos] = nT.y; qn.tb[npos] = nT.z; qn.id[npos] = id; qn.state[npos] = nstate;
-            if (GEN && rp.li) qn.es[npos] = nes;
         }
     }
     };
@@ -2482,6 +2539,7 @@ static int render_lane(rt_scene *this_, RenderLane &ln, const rt_camera *cam, co
     const int rr_extend = env_int("RT_AMD_RR_EXTEND", 1) ? 2 : 0;
     const int rr_shadow = env_int("RT_AMD_RR_SHADOW", 1) ? 2 : 0;
     rp.rr_shade = env_int("RT_AMD_RR_SHADE", 0);
+    rp.pack_shadow = env_int("RT_AMD_PACK_SHADOW", 1);
     rp.merge_mirror = (this_->classes[RT_MAT_MATTE] && this_->classes[RT_MAT_MIRROR]) ? std::max(0, std::min(2, env_int("RT_AMD_MERGE_MIRROR", 2))) : 0;
     // incoherent bounces of LDS scenes: lanes carry long rays over and refill (k_extend_carry); camera rays stay round-based
     const int carry_from = env_int("RT_AMD_CARRY_FROM", 1);

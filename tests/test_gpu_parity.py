@@ -379,6 +379,8 @@ def test_frame_walks_give_identical_images(name, w, device_scene, host_scene, mo
                 # every bounce through its own launches instead of k_finish for the late ones (the first render of a scene learns the
                 # switch-over bounce, so the renders after it use k_finish unless told otherwise)
                 {"RT_AMD_FINISH": "0"},
+                # fused shading kernels: every wave walks the shadow rays of its own 64 paths at once instead of collecting full waves of them
+                {"RT_AMD_PACK_SHADOW": "0"}, {"RT_AMD_PACK_SHADOW": "0", "RT_AMD_FINISH": "0"},
                 {"RT_AMD_FUSE_SHADOW": "0", "RT_AMD_CARRY_FROM": "1000", "RT_AMD_MERGE_MIRROR": "0", "RT_AMD_FRAME_BLOCKS_PER_CU": "4"})
     for env in variants:
         for k, v in env.items():
