@@ -229,7 +229,7 @@ def frame_roofline(ds, cam, sx, sy, name, W, H, n_paths_per_s, stats):
     """What bounds the frame.  Scenes that fit LDS (Cornell) are bound by VALU issue: the fraction reported is the share of the
     chip's VALU lane-slots that did useful work = VALU busy x lane utilisation, both from the PMC summary of the same frame
     committed under profiles/ (rocprofv3 cannot wrap its own caller); the per-class kernel times are measured here, on one lane (the events
-    that bracket every launch serialise them), while the timed frames run two lanes at once."""
+    that bracket every launch serialise them), while the timed frames run two or three lanes at once."""
     _, st = ds.render_device(cam, ra.make_opts(sx, sy, max_depth=MAX_DEPTH, flags=ra.capi.RT_RENDER_TIME_KERNELS))
     parts = {"trace": st.seconds_trace, "shade": st.seconds_shade, "shadow": st.seconds_shadow, "other": st.seconds_other}
     tot = sum(parts.values()) or 1.0
@@ -250,8 +250,8 @@ def frame_roofline(ds, cam, sx, sy, name, W, H, n_paths_per_s, stats):
             pass
     if pmc:
         # The counters (and the per-class times above) come from runs in which the launches are serialised: rocprofv3 runs one dispatch at
-        # a time while it counts, and the events of RT_RENDER_TIME_KERNELS keep the render on one lane.  The timed frame overlaps two lanes
-        # on two streams; it issues the same instructions in less time, so its share of useful lane-slots is the serialised share times
+        # a time while it counts, and the events of RT_RENDER_TIME_KERNELS keep the render on one lane.  The timed frame overlaps two or three lanes,
+        # each on its own stream; it issues the same instructions in less time, so its share of useful lane-slots is the serialised share times
         # (serialised frame time / timed frame time).
         serial = pmc["frame"]["useful_lane_fraction"]
         overlap = tot / stats["seconds"] if stats["seconds"] > 0 else 1.0
@@ -259,7 +259,7 @@ def frame_roofline(ds, cam, sx, sy, name, W, H, n_paths_per_s, stats):
                     "frac": round(serial * overlap, 4), "serialised": {"useful_lane_fraction": serial, "valu_busy": pmc["frame"]["valu_busy"],
                                                                      "lane_utilisation": pmc["frame"]["lane_utilisation"], "frame_seconds": round(tot, 5)},
                     "timed_frame_seconds": round(stats["seconds"], 5), "overlap_factor": round(overlap, 4),
-                    "derivation": "frac = serialised.useful_lane_fraction (PMC, one dispatch at a time) x serialised.frame_seconds / timed_frame_seconds (two lanes overlapped)",
+                    "derivation": "frac = serialised.useful_lane_fraction (PMC, one dispatch at a time) x serialised.frame_seconds / timed_frame_seconds (render lanes overlapped)",
                     "per_kernel": pmc["kernels"], "pmc_source": pmc_src, "pmc_sample": pmc.get("sample")})
     else:
         out.update({"achieved": None, "peak": 1.0, "unit": "fraction of VALU lane-slots doing useful work", "frac": None})

@@ -2530,6 +2530,7 @@ static int render_lane(rt_scene *this_, RenderLane &ln, const rt_camera *cam, co
     // persistent lanes win on deep trees once the rays are incoherent.  Measured, Msamples/s: Cornell 1174 round-based
     // vs 1002 persistent; spheres 3445 vs 3169; helmet 273 round-based, 328 persistent, 346 with only bounce 0 round-based.
     const int round_bounces = env_int("RT_AMD_FRAME_ROUND_BOUNCES", small_tree ? 1 << 20 : 1);
+    const int shadow_round_bounces = env_int("RT_AMD_SHADOW_ROUND_BOUNCES", round_bounces);
     const int round_pairs = (this_->interior_depth <= 8 && env_int("RT_AMD_ROUND_PAIRS", 1)) ? 1 : 0;
     const int round_quads = (this_->dev.quads && env_int("RT_AMD_ROUND_PAIRS", 1)) ? 1 : 0;
     // Round-robin chunks or contiguous shares for the round-based kernels (block_chunks).  Measured at 800x800, 256 spp, Msamples/s,
@@ -2616,7 +2617,7 @@ static int render_lane(rt_scene *this_, RenderLane &ln, const rt_camera *cam, co
                 if (this_->classes[RT_MAT_ROUGHGLASS]) launch_shade<RT_MAT_ROUGHGLASS>(this_, ln, rp, b, q[cq], q[cq ^ 1], hb, ucap, useg, sq, nseg, fuse_shadow, lbuf, bstats);
                 tm.mark(RT_TIME_SHADE);
                 if (this_->dev.n_lights > 0 && !fuse_shadow && rp.nee_mode != 2) {
-                    if (frame_old || b < round_bounces || all_lights) {      // (k_shadow_pl borrows the hit buffer, which the next light's shading still reads)
+                    if (frame_old || b < shadow_round_bounces || all_lights) {      // (k_shadow_pl borrows the hit buffer, which the next light's shading still reads)
                         if (b >= shadow_carry_from)
                             hipLaunchKernelGGL(k_shadow_carry, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, b, sq, useg, lbuf, counts, bstats);
                         else if (lds_scene)
