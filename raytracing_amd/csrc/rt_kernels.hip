@@ -342,6 +342,21 @@ __device__ __forceinline__ void stage_pairs_lds(const DevScene &sc, float4 *s_pa
     for (int i = threadIdx.x; i < 4 * sc.n_pairs; i += RT_BLOCK) s_pairs[(i & 3) * (RT_LDS_SCENE_NODES / 2) + (i >> 2)] = sc.pairs[i];
 }
 
+// Shadow ray over the LDS copy of a small scene's pair records (bvh.cpp:284-320; tMax = 1 - ShadowEpsilon, interaction.h:27-32):
+// interior nodes first, the leaves they lead to afterwards (trace_any_deferred); RT_ANY_DEFERRED=0 builds the walk in the
+// reference's order instead (same answers).
+#ifndef RT_ANY_DEFERRED
+#define RT_ANY_DEFERRED 1
+#endif
+template <class Stack>
+__device__ __forceinline__ void trace_shadow_lds(const DevScene &sc, const float4 *s_pairs, const float4 *s_slots, F3 o, F3 d, Stack &st, LaneTrav &L) {
+#if RT_ANY_DEFERRED
+    trace_any_deferred<RT_LDS_SCENE_NODES / 2, RT_FRAME_RING>(sc, s_pairs, s_slots, o, d, 1.f - 0.0001f, st, L);
+#else
+    trace_one<true, RT_LDS_SCENE_NODES / 2>(sc, s_pairs, s_slots, o, d, 1.f - 0.0001f, st, L);
+#endif
+}
+
 template <bool LDS_SCENE>
 __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
                                                       uint32_t segcap, float4 *lbuf, BounceCounts *counts, BounceStats *stats, int *spill, int fast_walk) {
@@ -1178,7 +1193,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MAT == RT_MAT_MATTE || MAT == RT_MAT_MIR
                 bool lit = false;
                 if (walker) {
                     LaneTrav L = {};
-                    trace_one<true, RT_LDS_SCENE_NODES / 2>(sc_in, s_pairs, s_slots, wo_, wd_, 1.f - 0.0001f, pst, L);
+                    trace_shadow_lds(sc_in, s_pairs, s_slots, wo_, wd_, pst, L);
                     lit = !L.found;
                 }
                 if (lit) {
@@ -1288,7 +1303,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_finish(DevScene sc_in, RenderParam
         else trace_one<false, 1, true>(sc_in, sc_in.quads, sc_in.slots, o, d, RT_INF, gst, L);
     };
     auto trace_shadow = [&](F3 o, F3 d, LaneTrav &L) {            // tMax = 1 - ShadowEpsilon (interaction.h:27-32)
-        if (LDS_SCENE) trace_one<true, RT_LDS_SCENE_NODES / 2>(sc_in, s_pairs, t_slots, o, d, 1.f - 0.0001f, pst, L);
+        if (LDS_SCENE) trace_shadow_lds(sc_in, s_pairs, t_slots, o, d, pst, L);
         else trace_one<true, 1, true>(sc_in, sc_in.quads, sc_in.slots, o, d, 1.f - 0.0001f, gst, L);
     };
     const uint32_t total = segment_prefix(counts[bounce].queue, s_prefix, s_wave);     // its barriers order the copies above before their use
@@ -1413,7 +1428,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, Sh
         bool occluded;   // tMax = 1 - ShadowEpsilon
         if (LDS_SCENE && (fast_walk & 1)) {
             LaneTrav L = {};
-            trace_one<true, RT_LDS_SCENE_NODES / 2>(sc, s_nodes, s_slots, o, d, 1.f - 0.0001f, pst, L);
+            trace_shadow_lds(sc, s_nodes, s_slots, o, d, pst, L);
             occluded = L.found;
         } else if (!LDS_SCENE && (fast_walk & 1)) {
             LaneTrav L = {};

@@ -327,6 +327,74 @@ __device__ __forceinline__ LeafOut lane_leaf(const DevScene &sc, const float4 *s
     return r;
 }
 
+// Any-hit walk of a shadow ray over pair records in LDS, leaves deferred.
+// A shadow ray's tMax never changes and only the answer "is anything hit" is wanted, so the order of the visits is free: a leaf is
+// reached by BVHAccel::IntersectP (bvh.cpp:284-320) exactly when its box and the boxes of all its ancestors pass
+// Bounds3::IntersectP against that fixed tMax (unless an earlier hit has already ended the walk), and the answer is whether any
+// primitive of any such leaf is hit.  This walk makes the same box tests on the same numbers and the same primitive tests, in two
+// phases: first the interior nodes alone — every lane of the wave takes interior steps in lockstep until its stack is empty, and
+// the leaves it reaches are only noted — then the noted leaves, one primitive per lane per step, until a lane has a hit or its
+// list is empty.  A wave waits for its slowest ray either way, so the early exit of an occluded ray in the middle of the walk saved
+// nothing, while the alternation between interior steps and leaf tests cost idle lanes on every change of phase.
+// The stack is the index half of `st` (RT_FRAME_RING entries: the caller guarantees that many interior levels at most); the list of
+// leaves is its tMin half, which a fixed-tMax walk does not need.  A lane whose list is nearly full stops walking; the phases then
+// repeat for it.
+template <int KSTRIDE, int RING, class Stack>
+__device__ __forceinline__ bool trace_any_deferred(const DevScene &sc, const float4 *pairs, const float4 *slots, F3 o, F3 d, float tmax, Stack &st, LaneTrav &L) {
+    uint32_t dummy = 0;
+    bool has_cur = lane_begin<false>(sc, L, st, o, d, tmax, dummy);
+    int *nodes = st.lds_i, *leaves = (int *)st.lds_t;       // [entry * RT_BLOCK], this lane's column
+    int sp = 0, nl = 0;
+    uint32_t cur = sc.root_info;
+    if (has_cur && (cur & RT_PAIR_LEAF)) { leaves[0] = (int)cur; nl = 1; has_cur = false; }     // a tree that is one leaf
+    bool found = false;
+    int slot = 0, left = 0;                                   // primitives of the leaf under test: next slot, how many are left
+    while (true) {
+        // ---- interior nodes
+        while (has_cur && nl <= RING - 2) {
+            const float4 *P = pairs + (KSTRIDE == 1 ? 4 : 1) * (size_t)cur;
+            float4 q0 = P[0], q1 = P[KSTRIDE], q2 = P[2 * KSTRIDE], q3 = P[3 * KSTRIDE];
+            const uint32_t iL = __float_as_uint(q3.x), iR = __float_as_uint(q3.y);
+            float tL, tR;
+            bool okL, okR;
+            if (L.plain) {
+                okL = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, L.o, L.invDir, tL);
+                okR = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, L.o, L.invDir, tR);
+            } else {
+                okL = slab_partial(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, L.o, L.invDir, L.negx, L.negy, L.negz, tL);
+                okR = slab_partial(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, L.o, L.invDir, L.negx, L.negy, L.negz, tR);
+            }
+            okL = okL && tL < L.tmax; okR = okR && tR < L.tmax;      // geometry.h:913
+            const bool leafL = okL && (iL & RT_PAIR_LEAF) != 0, leafR = okR && (iR & RT_PAIR_LEAF) != 0;
+            if (leafL) { leaves[nl * RT_BLOCK] = (int)iL; nl++; }
+            if (leafR) { leaves[nl * RT_BLOCK] = (int)iR; nl++; }
+            const bool intL = okL && !leafL, intR = okR && !leafR;
+            if (intL && intR) { nodes[sp * RT_BLOCK] = (int)iR; sp++; }
+            has_cur = intL || intR;
+            cur = intL ? iL : iR;
+            if (!has_cur && sp > 0) { sp--; cur = (uint32_t)nodes[sp * RT_BLOCK]; has_cur = true; }
+        }
+        // ---- the leaves noted so far, one primitive per step
+        while (!found && (left > 0 || nl > 0)) {
+            if (left == 0) {
+                nl--;
+                LaneTrav E;                                   // lane_enter decodes the info word (first slot, count)
+                lane_enter(sc, E, (uint32_t)leaves[nl * RT_BLOCK], true);
+                slot = E.cur; left = E.count;
+            }
+            float4 r0 = slots[3 * (size_t)slot], r1 = slots[3 * (size_t)slot + 1], r2 = slots[3 * (size_t)slot + 2];
+            float t, b0, b1, b2;
+            if (__float_as_uint(r2.y) & RT_SLOT_SPHERE) found = sphere_test(sc.spheres + 32 * (size_t)__float_as_int(r2.w), L.o, L.d, L.tmax, t);
+            else found = triangle_test_sheared(f3(r0.x, r0.y, r0.z), f3(r0.w, r1.x, r1.y), f3(r1.z, r1.w, r2.x), L.o, L.shear, L.tmax, t, b0, b1, b2);
+            slot++; left--;
+        }
+        if (found) has_cur = false;
+        if (__ballot(has_cur) == 0) break;
+    }
+    L.found = found;
+    return found;
+}
+
 // One ray per lane, run to completion (the round-based frame kernels): interior steps until every lane of the wave that is
 // still walking has reached a leaf or finished, then the leaf tests together — the same pair records, slab tests and
 // per-ray constants as the persistent walk, without its scheduling.
