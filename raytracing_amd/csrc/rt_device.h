@@ -129,8 +129,10 @@ __device__ __forceinline__ F3 offset_ray_origin(F3 p, F3 n, F3 w) {
 __device__ __forceinline__ void philox4x32(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        // (one 32 x 32 -> 64 bit multiply-add instruction per product instead of a low and a high multiply)
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
+        uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
         uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

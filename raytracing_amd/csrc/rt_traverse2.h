@@ -152,8 +152,8 @@ __device__ __forceinline__ bool stack_next(const LaneTrav &L, Stack &st, uint32_
 __device__ __forceinline__ bool finite_nonzero(float v) { float a = fabsf(v); return a > 0.f && a < RT_INF; }
 // Start a ray: slab-test the root (the reference's first loop iteration) and enter it.
 // Returns whether the root is to be entered (info word sc.root_info).
-template <bool COUNT, class Stack>
-__device__ __forceinline__ bool lane_begin(const DevScene &sc, LaneTrav &L, Stack &st, F3 o, F3 d, float tmax, uint32_t &nNodes) {
+// The per-ray constants of a walk (bvh.cpp:250-252, triangle.cpp:62-72).
+__device__ __forceinline__ void lane_setup(LaneTrav &L, F3 o, F3 d, float tmax) {
     L.o = o; L.d = d; L.tmax = tmax;
     L.invDir = f3(1.f / d.x, 1.f / d.y, 1.f / d.z);
     L.negx = L.invDir.x < 0; L.negy = L.invDir.y < 0; L.negz = L.invDir.z < 0;
@@ -162,6 +162,10 @@ __device__ __forceinline__ bool lane_begin(const DevScene &sc, LaneTrav &L, Stac
               fabsf(o.z) < RT_INF;
     L.hitSlot = -1; L.b0 = L.b1 = L.b2 = 0.f; L.found = false;
     L.shear = ray_shear(d, L.invDir);
+}
+template <bool COUNT, class Stack>
+__device__ __forceinline__ bool lane_begin(const DevScene &sc, LaneTrav &L, Stack &st, F3 o, F3 d, float tmax, uint32_t &nNodes) {
+    lane_setup(L, o, d, tmax);
     st.reset();
     bool have = false;
     if (sc.n_nodes != 0) {
@@ -340,9 +344,7 @@ __device__ __forceinline__ LeafOut lane_leaf(const DevScene &sc, const float4 *s
 // leaves is its tMin half, which a fixed-tMax walk does not need.  A lane whose list is nearly full stops walking; the phases then
 // repeat for it.
 template <int KSTRIDE, int RING, class Stack>
-__device__ __forceinline__ bool trace_any_deferred(const DevScene &sc, const float4 *pairs, const float4 *slots, F3 o, F3 d, float tmax, Stack &st, LaneTrav &L) {
-    uint32_t dummy = 0;
-    bool has_cur = lane_begin<false>(sc, L, st, o, d, tmax, dummy);
+__device__ __forceinline__ bool trace_any_deferred_from(const DevScene &sc, const float4 *pairs, const float4 *slots, bool has_cur, Stack &st, LaneTrav &L) {
     int *nodes = st.lds_i, *leaves = (int *)st.lds_t;       // [entry * RT_BLOCK], this lane's column
     int sp = 0, nl = 0;
     uint32_t cur = sc.root_info;
@@ -394,6 +396,17 @@ __device__ __forceinline__ bool trace_any_deferred(const DevScene &sc, const flo
     L.found = found;
     return found;
 }
+template <int KSTRIDE, int RING, class Stack>
+__device__ __forceinline__ bool trace_any_deferred(const DevScene &sc, const float4 *pairs, const float4 *slots, F3 o, F3 d, float tmax, Stack &st, LaneTrav &L) {
+    uint32_t dummy = 0;
+    bool has_cur = lane_begin<false>(sc, L, st, o, d, tmax, dummy);       // the root's box (the reference's first loop iteration)
+    return trace_any_deferred_from<KSTRIDE, RING>(sc, pairs, slots, has_cur, st, L);
+}
+
+// (No walk at all was also measured for the 19-record Cornell tree: for a plain ray a leaf is reached exactly when its own box
+// passes — nested boxes and monotonic slab arithmetic make every ancestor pass too — so every lane can test all 20 leaf boxes in
+// lockstep and keep a bit mask.  It gives the same images and is 9 % slower than this walk: the tree rejects most leaves after six
+// or seven steps, and the uniform reads of every record double the LDS traffic.)
 
 // One ray per lane, run to completion (the round-based frame kernels): interior steps until every lane of the wave that is
 // still walking has reached a leaf or finished, then the leaf tests together — the same pair records, slab tests and
