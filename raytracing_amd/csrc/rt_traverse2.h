@@ -150,8 +150,6 @@ __device__ __forceinline__ bool stack_next(const LaneTrav &L, Stack &st, uint32_
     return have;
 }
 __device__ __forceinline__ bool finite_nonzero(float v) { float a = fabsf(v); return a > 0.f && a < RT_INF; }
-// Start a ray: slab-test the root (the reference's first loop iteration) and enter it.
-// Returns whether the root is to be entered (info word sc.root_info).
 // The per-ray constants of a walk (bvh.cpp:250-252, triangle.cpp:62-72).
 __device__ __forceinline__ void lane_setup(LaneTrav &L, F3 o, F3 d, float tmax) {
     L.o = o; L.d = d; L.tmax = tmax;
@@ -163,6 +161,12 @@ __device__ __forceinline__ void lane_setup(LaneTrav &L, F3 o, F3 d, float tmax) 
     L.hitSlot = -1; L.b0 = L.b1 = L.b2 = 0.f; L.found = false;
     L.shear = ray_shear(d, L.invDir);
 }
+// Start a ray: slab-test the root (the reference's first loop iteration) and enter it.
+// Returns whether the root is to be entered (info word sc.root_info).
+// For a plain ray and an interior root the test is left out: whatever the walk does next is decided by the boxes of the root's
+// children (pair records) or grandchildren (quad records), and one of those can only pass if the root's box — their exact
+// componentwise union, under monotonic slab arithmetic — passes too, tMin < tMax included; a ray that misses the root then ends
+// after one step instead of none, with the same result.  (The counting variant keeps the test: it counts the reference's slab tests.)
 template <bool COUNT, class Stack>
 __device__ __forceinline__ bool lane_begin(const DevScene &sc, LaneTrav &L, Stack &st, F3 o, F3 d, float tmax, uint32_t &nNodes) {
     lane_setup(L, o, d, tmax);
@@ -170,9 +174,12 @@ __device__ __forceinline__ bool lane_begin(const DevScene &sc, LaneTrav &L, Stac
     bool have = false;
     if (sc.n_nodes != 0) {
         if (COUNT) nNodes++;
-        float tMin;
-        have = slab_partial(sc.root_box[0], sc.root_box[1], sc.root_box[2], sc.root_box[3], sc.root_box[4], sc.root_box[5], o, L.invDir, L.negx, L.negy, L.negz, tMin) &&
-               tMin < tmax;
+        if (!COUNT && L.plain && (sc.root_info & RT_PAIR_LEAF) == 0) have = true;
+        else {
+            float tMin;
+            have = slab_partial(sc.root_box[0], sc.root_box[1], sc.root_box[2], sc.root_box[3], sc.root_box[4], sc.root_box[5], o, L.invDir, L.negx, L.negy, L.negz, tMin) &&
+                   tMin < tmax;
+        }
     }
     return have;
 }
