@@ -1416,6 +1416,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, Sh
     TravStack st; st.lds = &s_stack[threadIdx.x]; st.spill = spill + gtid; st.spill_stride = nthreads; st.reset();
     PairStackT<8, true> gst; gst.lds_i = pst.lds_i; gst.lds_t = pst.lds_t; gst.cap = sc.quad_stack_cap;
     gst.spill_i = spill + gtid; gst.spill_t = (float *)(spill + (size_t)gst.cap * nthreads) + gtid; gst.spill_stride = nthreads; gst.reset();
+    InfoStack<8> ist; ist.lds = pst.lds_i; ist.spill = spill + gtid; ist.spill_stride = nthreads; ist.cap = gst.cap; ist.reset();
     const ChunkLoop cl = block_chunks(total, fast_walk & 2);
     uint32_t seg = cl.start < cl.end ? segment_of(s_prefix, cl.start) : 0;
     for (uint32_t base = cl.start; base < cl.end; base += cl.stride) {
@@ -1432,7 +1433,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, int bounce, Sh
             occluded = L.found;
         } else if (!LDS_SCENE && (fast_walk & 1)) {
             LaneTrav L = {};
+#if RT_ANY_DEFERRED
+            trace_any_deferred_quads<8>(sc, sc.quads, sc.slots, o, d, 1.f - 0.0001f, ist, (int *)pst.lds_t, L);
+#else
             trace_one<true, 1, true>(sc, sc.quads, sc.slots, o, d, 1.f - 0.0001f, gst, L);
+#endif
             occluded = L.found;
         } else if (LDS_SCENE) { LdsFetch lf; lf.nodes = s_nodes; lf.slots = s_slots; occluded = traverse<true, false>(sc, lf, o, d, 1.f - 0.0001f, st, h, c0, c1); }
         else { GlobalFetch gf; gf.nodes = sc.nodes; gf.slots = sc.slots; occluded = traverse<true, false>(sc, gf, o, d, 1.f - 0.0001f, st, h, c0, c1); }
@@ -1703,6 +1708,8 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_shadow_pl(DevScene sc, int boun
     st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     RayArrays ra = {sq.ox, sq.oy, sq.oz, sq.dx, sq.dy, sq.dz};
     // tMax = 1 - ShadowEpsilon (interaction.h SpawnRayTo)
+    // (Deferring the leaves here as trace_any_deferred_quads does was measured on the helmet: 0.235 s against 0.237 s for the frame's shadow rays — lanes
+    // that refill gain from the early exit of an occluded ray, and the phase vote already keeps them busy.)
     trace_share<true, MODE>(sc, recs, slots, ra, 1.f - 0.0001f, total, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE],
                             [&](uint32_t i, const LaneTrav &L) { occluded[i] = L.found ? 1 : 0; });
     __threadfence_block();

@@ -415,6 +415,114 @@ __device__ __forceinline__ bool trace_any_deferred(const DevScene &sc, const flo
 // lockstep and keep a bit mask.  It gives the same images and is 9 % slower than this walk: the tree rejects most leaves after six
 // or seven steps, and the uniform reads of every record double the LDS traffic.)
 
+// The deferred any-hit walk over quad records in global memory (trees too large for LDS), for kernels that run one ray per lane to
+// completion.  Same reasoning as trace_any_deferred: every candidate of a quad step is accepted or rejected for good when the step is
+// made (the candidate's `now` of quad_side: all of the reference's conditions on the child and on the grandchild against the
+// fixed tMax), accepted leaves are noted, accepted interior nodes are walked in any order.  The node stack keeps indices only
+// (ring of RING entries in LDS, older entries spilled to global memory: InfoStack); the leaf list is the other half of the
+// kernel's LDS stack area.
+template <int RING>
+struct InfoStack {
+    int *lds;                       // &shared[0][threadIdx.x], stride RT_BLOCK
+    int *spill; size_t spill_stride; int cap;
+    int sp, lo;                     // entries [lo, sp) are in the ring
+    __device__ __forceinline__ void reset() { sp = 0; lo = 0; }
+    __device__ __forceinline__ void push(int info) {
+        if (sp - lo == RING) {
+            if (lo < cap) spill[(size_t)lo * spill_stride] = lds[(lo & (RING - 1)) * RT_BLOCK];
+            lo++;
+        }
+        lds[(sp & (RING - 1)) * RT_BLOCK] = info;
+        sp++;
+    }
+    __device__ __forceinline__ bool pop(int &info) {      // false: the entry was beyond the spill area's capacity (trees that deep are refused at scene creation)
+        sp--;
+        if (sp < lo) {
+            lo = sp;
+            if (sp < cap) { info = spill[(size_t)sp * spill_stride]; return true; }
+            info = 0; return false;
+        }
+        info = lds[(sp & (RING - 1)) * RT_BLOCK];
+        return true;
+    }
+};
+// Per-lane state of a deferred any-hit walk over quad records, beyond the ray's constants in LaneTrav.
+struct AnyWalk {
+    uint32_t cur; bool has_cur;     // interior node to visit next
+    int nl;                         // leaves noted and not yet tested (info words in the lane's column of `leaves`)
+    int slot, left;                 // primitives of the leaf under test: next slot, how many are left
+    bool found;
+};
+// Ray constants and the root (lane_begin's reasoning: an interior root's own test is implied for a plain ray).
+template <int RING>
+__device__ __forceinline__ void any_walk_begin(const DevScene &sc, LaneTrav &L, AnyWalk &A, InfoStack<RING> &st, int *leaves, F3 o, F3 d, float tmax) {
+    lane_setup(L, o, d, tmax);
+    st.reset();
+    A.has_cur = false; A.nl = 0; A.slot = 0; A.left = 0; A.found = false; A.cur = sc.root_info;
+    if (sc.n_nodes != 0) {
+        if (L.plain && (sc.root_info & RT_PAIR_LEAF) == 0) A.has_cur = true;
+        else {
+            float tMin;
+            A.has_cur = slab_partial(sc.root_box[0], sc.root_box[1], sc.root_box[2], sc.root_box[3], sc.root_box[4], sc.root_box[5], o, L.invDir, L.negx, L.negy, L.negz, tMin) &&
+                        tMin < tmax;
+        }
+    }
+    if (A.has_cur && (A.cur & RT_PAIR_LEAF)) { leaves[0] = (int)A.cur; A.nl = 1; A.has_cur = false; }     // a tree that is one leaf
+}
+// One quad record: the candidates that pass are noted (leaves) or walked / pushed (interior nodes); at most four leaves are added.
+template <bool PLAIN, int RING>
+__device__ __forceinline__ void any_walk_step(const float4 *quads, const LaneTrav &L, AnyWalk &A, InfoStack<RING> &st, int *leaves) {
+    const float4 *Q = quads + 8 * (size_t)A.cur;
+    float4 q0 = Q[0], q1 = Q[1], q2 = Q[2], q3 = Q[3], q4 = Q[4], q5 = Q[5], q6 = Q[6];
+    uint32_t meta = ((const uint32_t *)Q)[28];
+    QuadCand c[4];
+    quad_side<PLAIN>(L, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, __float_as_uint(q6.x), __float_as_uint(q6.y), (meta & 64u) != 0,
+                     (int)((meta >> 2) & 3u), c[0], c[1]);
+    quad_side<PLAIN>(L, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, __float_as_uint(q6.z), __float_as_uint(q6.w), (meta & 128u) != 0,
+                     (int)((meta >> 4) & 3u), c[2], c[3]);
+    A.has_cur = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!c[k].now) continue;
+        if (c[k].info & RT_PAIR_LEAF) { leaves[A.nl * RT_BLOCK] = (int)c[k].info; A.nl++; }
+        else if (!A.has_cur) { A.cur = c[k].info; A.has_cur = true; }
+        else st.push((int)c[k].info);
+    }
+    if (!A.has_cur && st.sp > 0) { int i; A.has_cur = st.pop(i); A.cur = (uint32_t)i; }
+}
+// One primitive of the noted leaves (the caller checks that there is one: A.left > 0 || A.nl > 0).
+__device__ __forceinline__ void any_walk_test(const DevScene &sc, const float4 *slots, const LaneTrav &L, AnyWalk &A, const int *leaves) {
+    if (A.left == 0) {
+        A.nl--;
+        LaneTrav E;                                           // lane_enter decodes the info word (first slot, count)
+        lane_enter(sc, E, (uint32_t)leaves[A.nl * RT_BLOCK], true);
+        A.slot = E.cur; A.left = E.count;
+    }
+    float4 r0 = slots[3 * (size_t)A.slot], r1 = slots[3 * (size_t)A.slot + 1], r2 = slots[3 * (size_t)A.slot + 2];
+    float t, b0, b1, b2;
+    if (__float_as_uint(r2.y) & RT_SLOT_SPHERE) A.found = sphere_test(sc.spheres + 32 * (size_t)__float_as_int(r2.w), L.o, L.d, L.tmax, t);
+    else A.found = triangle_test_sheared(f3(r0.x, r0.y, r0.z), f3(r0.w, r1.x, r1.y), f3(r1.z, r1.w, r2.x), L.o, L.shear, L.tmax, t, b0, b1, b2);
+    A.slot++; A.left--;
+}
+// One ray per lane, run to completion: interior nodes until the stack is empty or the list is nearly full, then the noted leaves.
+template <int RING>
+__device__ __forceinline__ bool trace_any_deferred_quads(const DevScene &sc, const float4 *quads, const float4 *slots, F3 o, F3 d, float tmax, InfoStack<RING> &st,
+                                                         int *leaves, LaneTrav &L) {
+    AnyWalk A;
+    any_walk_begin(sc, L, A, st, leaves, o, d, tmax);
+    while (true) {
+        while (A.has_cur && A.nl <= RING - 4) {
+            if (L.plain) any_walk_step<true>(quads, L, A, st, leaves);
+            else any_walk_step<false>(quads, L, A, st, leaves);
+        }
+        while (!A.found && (A.left > 0 || A.nl > 0)) any_walk_test(sc, slots, L, A, leaves);
+        if (A.found) A.has_cur = false;
+        if (__ballot(A.has_cur) == 0) break;
+    }
+    L.found = A.found;
+    return A.found;
+}
+
 // One ray per lane, run to completion (the round-based frame kernels): interior steps until every lane of the wave that is
 // still walking has reached a leaf or finished, then the leaf tests together — the same pair records, slab tests and
 // per-ray constants as the persistent walk, without its scheduling.
