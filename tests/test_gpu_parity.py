@@ -392,6 +392,25 @@ def test_frame_walks_give_identical_images(name, w, device_scene, host_scene, mo
         assert np.array_equal(img, base), env
 
 
+@pytest.mark.parametrize("name,w,ordered", [("cornell", 800, {"RT_AMD_SHADOW_CARRY_FROM": "0"}), ("cornell", 800, {"RT_AMD_FRAME_NODE_WALK": "1", "RT_AMD_ROUND_PAIRS": "0"}),
+                                            ("helmet", 720, {"RT_AMD_FRAME_ROUND_BOUNCES": "0"}), ("cornell_env", 400, {"RT_AMD_SHADOW_CARRY_FROM": "0"})])
+def test_deferred_shadow_walks_answer_as_the_ordered_walks(name, w, ordered, device_scene, host_scene, monkeypatch):
+    """Shadow rays of the round-based kernels visit the interior nodes first and the leaves afterwards (their tMax is fixed, so the
+    order of BVHAccel::IntersectP is free); the persistent-lane kernels, k_shadow_carry and the node walk keep the reference's order.
+    Ten million paths and more: one differing any-hit answer would change a radiance sum, so the images must be identical to the
+    last bit and the ray counts equal."""
+    ds = device_scene(name)
+    cam = host_scene(name).camera(w, w)
+    opts = ra.make_opts(4, 4)
+    monkeypatch.setenv("RT_AMD_RENDER_LANES", "1")
+    base, st = ds.render(cam, opts)
+    for k, v in ordered.items():
+        monkeypatch.setenv(k, v)
+    img, st2 = ds.render(cam, opts)
+    assert st.rays_shadow > 0 and (st2.rays_closest, st2.rays_shadow) == (st.rays_closest, st.rays_shadow)
+    assert np.array_equal(img, base)
+
+
 @pytest.mark.parametrize("name,w,sx", [("cornell", 800, 6), ("helmet", 720, 6)])
 def test_render_lanes_share_the_samples(name, w, sx, device_scene, host_scene, monkeypatch):
     """Renders of 16 Mi paths and more run as several lanes at once, each over its share of the samples on its own stream, and the lane
