@@ -206,8 +206,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_batch(DevScene sc, size_t n,
 
 // Batch trace over pair nodes with persistent lanes (rt_traverse2.h).  Each wave owns a contiguous range of rays.
 #define RT_LEAF_MIN_LANES 20
+#ifndef RT_LEAF_LOAD_AHEAD
+#define RT_LEAF_LOAD_AHEAD 1
+#endif
+#ifndef RT_TRACE_OCC
+#define RT_TRACE_OCC 4          // waves per SIMD the batch trace kernels are compiled for (they are launched four blocks to a CU: five lose to L2 thrash)
+#endif
 template <bool ANY, bool COUNT, bool QUAD>
-__global__ __launch_bounds__(RT_BLOCK, 5) void k_trace_pairs(DevScene sc, size_t n, const float *__restrict__ rays, int aos, int *out_prim, float *out_t,
+__global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene sc, size_t n, const float *__restrict__ rays, int aos, int *out_prim, float *out_t,
                                                            float *out_b1, float *out_b2, uint8_t *out_any, int *spill, unsigned long long *work, int leaf_min) {
     constexpr int RING = QUAD ? RT_QUAD_STACK : RT_PAIR_STACK;
     __shared__ int s_si[RING * RT_BLOCK];
@@ -270,13 +276,22 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_trace_pairs(DevScene sc, size_t
         uint32_t info = 0; bool have = false;
         bool walk = L.mode == RT_LANE_WALK, leaf = L.mode == RT_LANE_LEAF;
         uint64_t lm = __ballot(leaf), wm = __ballot(walk);
+        const bool leafrun = leaf && (__popcll(lm) >= leaf_min || wm == 0);
+#if RT_LEAF_LOAD_AHEAD
+        // the leaf lanes' triangle loads go out before the walkers' step, so that the two fetches of this iteration are in flight together
+        float4 pre[3];
+        if (leafrun) { const float4 *sl = sc.slots + 3 * (size_t)L.cur; pre[0] = sl[0]; pre[1] = sl[1]; pre[2] = sl[2]; }
+#endif
         if (QUAD) {
             if (__ballot(walk && !L.plain) == 0 && !exact_slabs) { if (walk) lane_walk_quad<true>(sc.quads, L, st, info, have); }     // the whole wave takes one version
             else if (walk) lane_walk_quad<false>(sc.quads, L, st, info, have);
         } else if (walk) lane_walk<COUNT, false>(sc.pairs, L, st, nNodes, info, have);
-        bool leafrun = leaf && (__popcll(lm) >= leaf_min || wm == 0);
         if (leafrun) {
+#if RT_LEAF_LOAD_AHEAD
+            LeafOut r = lane_leaf<ANY, COUNT>(sc, sc.slots, L, st, nTests, pre);
+#else
             LeafOut r = lane_leaf<ANY, COUNT>(sc, sc.slots, L, st, nTests);
+#endif
             L.found = r.found; L.tmax = r.tmax; L.hitSlot = r.hitSlot; L.b0 = r.b0; L.b1 = r.b1; L.b2 = r.b2;
             info = r.info; have = r.have;
         }

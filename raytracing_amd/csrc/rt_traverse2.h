@@ -303,13 +303,17 @@ __device__ __forceinline__ void lane_walk_quad(const float4 *quads, const LaneTr
 
 // Test the primitives of the pending leaf (bvh.cpp:258-261 / 294-299) and pick the next node.
 struct LeafOut { bool found; float tmax; int hitSlot; float b0, b1, b2; uint32_t info; bool have; };
+// first: the three float4 of the leaf's first slot when the caller has loaded them already (so that the load could be issued ahead of
+// other work), else nullptr.
 template <bool ANY, bool COUNT, bool FIXED_POP = false, class Stack>
-__device__ __forceinline__ LeafOut lane_leaf(const DevScene &sc, const float4 *slots, const LaneTrav &L, Stack &st, uint32_t &nTests) {
+__device__ __forceinline__ LeafOut lane_leaf(const DevScene &sc, const float4 *slots, const LaneTrav &L, Stack &st, uint32_t &nTests, const float4 *first = nullptr) {
     LeafOut r; r.found = L.found; r.tmax = L.tmax; r.hitSlot = L.hitSlot; r.b0 = L.b0; r.b1 = L.b1; r.b2 = L.b2;
     bool stop = false;
     for (int i = 0; i < L.count && !stop; ++i) {
         int slot = L.cur + i;
-        float4 r0 = slots[3 * (size_t)slot], r1 = slots[3 * (size_t)slot + 1], r2 = slots[3 * (size_t)slot + 2];
+        float4 r0, r1, r2;
+        if (first && i == 0) { r0 = first[0]; r1 = first[1]; r2 = first[2]; }
+        else { r0 = slots[3 * (size_t)slot]; r1 = slots[3 * (size_t)slot + 1]; r2 = slots[3 * (size_t)slot + 2]; }
         uint32_t flags = __float_as_uint(r2.y);
         if (COUNT) nTests++;
         float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
