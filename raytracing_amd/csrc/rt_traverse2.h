@@ -342,6 +342,11 @@ __device__ __forceinline__ LeafOut lane_leaf(const DevScene &sc, const float4 *s
     return r;
 }
 
+// (test builds: -DRT_ANY_LIST_SQUEEZE=4 leaves room for almost no noted leaves, so that nearly every ray goes through the "list full:
+// test, then walk on" path of the deferred walks below)
+#ifndef RT_ANY_LIST_SQUEEZE
+#define RT_ANY_LIST_SQUEEZE 0
+#endif
 // Any-hit walk of a shadow ray over pair records in LDS, leaves deferred.
 // A shadow ray's tMax never changes and only the answer "is anything hit" is wanted, so the order of the visits is free: a leaf is
 // reached by BVHAccel::IntersectP (bvh.cpp:284-320) exactly when its box and the boxes of all its ancestors pass
@@ -364,7 +369,7 @@ __device__ __forceinline__ bool trace_any_deferred_from(const DevScene &sc, cons
     int slot = 0, left = 0;                                   // primitives of the leaf under test: next slot, how many are left
     while (true) {
         // ---- interior nodes
-        while (has_cur && nl <= RING - 2) {
+        while (has_cur && nl <= RING - 2 - RT_ANY_LIST_SQUEEZE) {
             const float4 *P = pairs + (KSTRIDE == 1 ? 4 : 1) * (size_t)cur;
             float4 q0 = P[0], q1 = P[KSTRIDE], q2 = P[2 * KSTRIDE], q3 = P[3 * KSTRIDE];
             const uint32_t iL = __float_as_uint(q3.x), iR = __float_as_uint(q3.y);
@@ -515,7 +520,7 @@ __device__ __forceinline__ bool trace_any_deferred_quads(const DevScene &sc, con
     AnyWalk A;
     any_walk_begin(sc, L, A, st, leaves, o, d, tmax);
     while (true) {
-        while (A.has_cur && A.nl <= RING - 4) {
+        while (A.has_cur && A.nl <= RING - 4 - RT_ANY_LIST_SQUEEZE) {
             if (L.plain) any_walk_step<true>(quads, L, A, st, leaves);
             else any_walk_step<false>(quads, L, A, st, leaves);
         }
