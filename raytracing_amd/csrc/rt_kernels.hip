@@ -9,10 +9,14 @@
 //                       finished lanes take new rays every two rounds), k_extend_pl (persistent lanes, large trees)
 //     k_shade<MAT>      one launch per material class present in the scene: BSDF build, next-event estimation, BSDF
 //                       sampling, Russian roulette (-> compacted next-bounce queue).  The shadow ray goes to a compacted
-//                       shadow queue, or — scenes that fit LDS — is traced on the spot.
+//                       shadow queue, or — scenes that fit LDS — is traced inside the kernel: a wave collects its shadow
+//                       rays until it holds 64 of them and walks those together.
 //                                                                             integrator.cpp:258-280, material.cpp, reflection.cpp
 //     k_shadow          any-hit traversal of the shadow queue, adds unoccluded light (k_shadow / k_shadow_pl; not launched when
 //                       the shading kernels trace their own shadow rays)       bvh.cpp:284-320, light.cpp:19-21
+//                       A shadow ray's tMax is fixed and only "is anything hit" is asked, so the kernels that run one ray per
+//                       lane to completion visit the interior nodes first and test the leaves they reach afterwards
+//                       (trace_any_deferred, rt_traverse2.h); closest-hit walks keep the reference's order throughout.
 //   k_accumulate        per-pixel sum of the pass's path radiances into the frame's sum buffer  integrator.cpp:324-337
 // Queues are segmented (one segment per producer block, block-local LDS counters, no global atomics on the data path); no
 // scattered float atomics are used: every path owns one float4 slot of radiance that only its own lane updates.
