@@ -201,6 +201,9 @@ typedef struct rt_render_stats {
     double   seconds_shade;    /* shading kernels (k_shade*; on scenes that fit LDS they trace the shadow ray too) */
     double   seconds_shadow;   /* any-hit kernels (k_shadow*)                                              */
     double   seconds_other;    /* ray generation, late-bounce kernel (k_finish), per-pixel accumulation    */
+    uint64_t rays_replayed;    /* closest-hit rays whose order-free test was not conclusive (two candidates nearly tied, a third leaf
+                                  in reach, a direction with a zero component) and that were walked again in the order of
+                                  BVHAccel::Intersect (bvh.cpp:247-282); counted in rays_closest once */
 } rt_render_stats;
 
 typedef struct rt_trace_stats {

@@ -76,7 +76,7 @@ class RenderOpts(C.Structure):
 class RenderStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64), ("iterations", C.c_uint64),
                 ("seconds_total", C.c_double), ("seconds_trace", C.c_double), ("seconds_shade", C.c_double),
-                ("seconds_shadow", C.c_double), ("seconds_other", C.c_double)]
+                ("seconds_shadow", C.c_double), ("seconds_other", C.c_double), ("rays_replayed", C.c_uint64)]
 
 
 class TraceStats(C.Structure):

@@ -71,6 +71,9 @@ struct DevScene {
     const float *light_cdf;   // n_lights + 1: cdf of the uniform Distribution1D over the lights (lightdistrib.cpp:12-15, sampling.h:16-27)
     float light_func_int;     // its funcInt
     int n_envs;
+    int root_implied;         // the root's box is bit for bit the union of its children's boxes (lane_begin may skip its test for plain rays)
+    const float4 *flat;       // 2 x float4 per leaf, in depth-first order: box min xyz, max x | max yz, info word (as in the pair records), -
+    int n_flat;               //   present (non-null) only for trees of at most RT_FLAT_MAX leaves whose boxes nest exactly (k_extend_flat)
 };
 
 struct F3 { float x, y, z; };

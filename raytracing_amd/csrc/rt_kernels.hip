@@ -47,6 +47,7 @@
 #define RT_SEG_BLOCKS 1280      // most queue segments = largest grid of the wavefront kernels (five blocks per CU)
 #define RT_SEG_PER_THREAD (RT_SEG_BLOCKS / RT_BLOCK)
 #define RT_FRAME_RING 8         // LDS ring entries per lane (node, tMin) of the frame kernels
+#define RT_FLAT_MAX 32          // most leaves of a tree that k_extend_flat tests leaf by leaf
 // The number of segments in use is the grid size of the frame kernels (gridDim.x, a multiple of RT_BLOCK): 1280 when every
 // kernel of the frame fits five blocks on a CU, 1024 when one of them (the metal / plastic shading kernels on large trees) does not.
 
@@ -60,7 +61,7 @@ struct BounceCounts {
     uint32_t shadow[RT_SEG_BLOCKS];                   // shadow rays produced by this bounce
     uint32_t cls[RT_NUM_CLASSES][RT_SEG_BLOCKS];      // paths per material class
 };
-struct BounceStats { uint32_t n_queue, n_shadow, pad0, pad1; };
+struct BounceStats { uint32_t n_queue, n_shadow, n_replay, pad1; };      // n_replay: rays k_extend_flat walked again in the reference's order
 
 struct PathQueue {   // SoA, capacity = cap
     float *ox, *oy, *oz, *dx, *dy, *dz, *tr, *tg, *tb;
@@ -580,6 +581,187 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_carry(DevScene sc, RenderPa
     }
     __syncthreads();
     if (threadIdx.x < RT_NUM_CLASSES) bc->cls[threadIdx.x][blockIdx.x] = s_cls[threadIdx.x];
+}
+
+// ------------------------------------------------------------ extend, flat --
+// Closest hit on a tree of at most RT_FLAT_MAX leaves without a walk.  Incoherent rays on a small tree spend their time
+// waiting for one another: the lanes of a wave need different numbers of interior steps to reach their leaves and change
+// between walking and testing at different moments (lane utilisation 0.42 in k_extend_carry on the Cornell box).  Here every
+// lane tests the boxes of ALL leaves, in lockstep, with the boxes coming from scalar loads (the same record for the whole
+// wave), keeps the three nearest boxes it pierces, and then tests the primitives of the nearest and of the second nearest leaf.
+//
+// Why this can give BVHAccel::Intersect's answer (bvh.cpp:247-282) although it ignores that function's visit order:
+//   * For a plain ray (slab_fast applies) on a tree whose interior boxes are bit for bit the unions of their children's, a
+//     leaf's own box passes the tMax-independent part of Bounds3::IntersectP exactly when every ancestor's does (nested
+//     boxes, monotonic slab arithmetic), so the set of leaves the reference can reach at all is the set found here.
+//   * A primitive's t and barycentrics do not depend on the ray's tMax; only its acceptance does.  The reference returns the
+//     primitive with the smallest t unless two candidates are nearly tied: at equal t the later-tested one wins
+//     (triangle.cpp:104-111 rejects only '>'), a hit may raise tMax by an ulp (tScaled <= tMax * det is tested, the rounded
+//     tScaled / det is stored), and a box entry distance next to a hit distance can fall on either side of '<'.  All of these
+//     need a second candidate — another primitive's t, or the accepted primitive's own leaf-box entry — within a few ulps
+//     of the smallest t.
+//   * So the lanes work with bands: a leaf is looked at unless its box entry lies beyond the best t so far times
+//     (1 + RT_FLAT_CULL_BAND); primitives are tested against that widened bound, the smallest and the second smallest t are kept;
+//     and the answer is taken only when the runner-up lies beyond max(best t, entry of the best's leaf) * (1 + RT_FLAT_TIE_BAND).
+//     Otherwise — and when a third leaf is still in reach, or the ray is not plain — the ray goes on the block's replay list,
+//     which the block walks afterwards in the reference's order (trace_one over the pair records, full waves again).
+//   * What the bands assume: no primitive's computed hit distance lies below the entry distance of its own leaf's box (or of an
+//     enclosing box) by more than the difference of the two bands, 0.1 % — a leaf skipped here cannot then hold a hit that the
+//     reference, arriving there with a larger tMax, would have accepted below the best t found here.
+#ifndef RT_FLAT_CULL_BAND
+#define RT_FLAT_CULL_BAND 1e-3f
+#endif
+#ifndef RT_FLAT_TIE_BAND
+#define RT_FLAT_TIE_BAND 1e-5f
+#endif
+__global__ __launch_bounds__(RT_BLOCK, 5) void k_extend_flat(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
+                                                           uint32_t segcap, float4 *lbuf, BounceCounts *counts, BounceStats *stats,
+                                                           const float4 *__restrict__ flat, int n_flat) {
+    __shared__ int s_stack[2 * RT_FRAME_RING * RT_BLOCK];                      // the replay walk's stack
+    __shared__ float4 s_nodes[2 * RT_LDS_SCENE_NODES], s_slots[3 * RT_LDS_SCENE_SLOTS];
+    __shared__ uint32_t s_info[RT_FLAT_MAX];
+    stage_pairs_lds(sc, s_nodes);
+    for (int i = threadIdx.x; i < 3 * sc.n_slots; i += RT_BLOCK) s_slots[i] = sc.slots[i];
+    if ((int)threadIdx.x < n_flat) s_info[threadIdx.x] = __float_as_uint(flat[2 * threadIdx.x + 1].z);
+    PairStackT<RT_FRAME_RING, false> pst; pst.lds_i = &s_stack[threadIdx.x]; pst.lds_t = (float *)&s_stack[RT_FRAME_RING * RT_BLOCK + threadIdx.x]; pst.reset();
+    __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE], s_cls[RT_NUM_CLASSES], s_replay;
+    BounceCounts *bc = counts + bounce;
+    if (threadIdx.x < RT_NUM_CLASSES) s_cls[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_replay = 0;
+    const uint32_t total = segment_prefix(bc->queue, s_prefix, s_wave);
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_queue = total;
+    if (threadIdx.x == 0) { bc->shadow[blockIdx.x] = 0; counts[bounce + 1].queue[blockIdx.x] = 0; }
+    const uint32_t seg_base = blockIdx.x * segcap;
+    uint32_t *replay_list = cls_list + (size_t)RT_NUM_CLASSES * cap + seg_base;
+    // hit record, emission / sky / termination (integrator.cpp:242-257); returns the material class the path is binned into, or -1
+    auto hand_in = [&](uint32_t i, bool found, int slot, float t, float b0, float b1, float b2, F3 d) -> int {
+        hb.slot[i] = found ? slot : -1; hb.t[i] = t; hb.b0[i] = b0; hb.b1[i] = b1; hb.b2[i] = b2;
+        const uint32_t state = q.state[i];
+        const int depth = state & 0xFFFF; const bool spec = (state >> 16) & 1;
+        F3 add = f3(0.f, 0.f, 0.f); bool terminal = false;
+        if (depth == 0 || spec || (sc.n_lights == 0 && !rp.li)) {      // rp.li: integrator.cpp:185-192, emission does not end the path and there is no sky
+            if (found) {
+                int li = sc.slot_light[slot];
+                if (li >= 0) {
+                    const DevLight &Lt = sc.lights[li];
+                    float4 nf = sc.frames[3 * slot];
+                    if (Lt.two_sided || dot3(f3(nf.x, nf.y, nf.z), -d) > 0) add = f3(Lt.Le[0], Lt.Le[1], Lt.Le[2]);   // light.h:73-75
+                    if (!black3(add) && !rp.li) terminal = true;
+                }
+            } else if (sc.n_lights == 0 && !rp.li) {
+                F3 ud = normalize3(d);
+                double tt = 0.5 * (ud.y + 1.0);
+                float a = (float)(1.0 - tt), b = (float)tt;
+                add = f3(1.0f * a + 0.5f * b, 1.0f * a + 0.7f * b, 1.0f * a + 1.0f * b);
+            }
+        }
+        if (!found || depth >= rp.max_depth) terminal = true;
+        if (!black3(add)) {
+            uint32_t id = q.id[i];
+            float4 Lr = lbuf[id];
+            Lr.x += q.tr[i] * add.x; Lr.y += q.tg[i] * add.y; Lr.z += q.tb[i] * add.z;
+            lbuf[id] = Lr;
+        }
+        int cls = -1;
+        if (!terminal) { cls = sc.materials[sc.slot_material[slot]].kind; if (rp.merge_mirror == 1 && cls == RT_MAT_MIRROR) cls = RT_MAT_MATTE; }
+        return cls;
+    };
+    auto bin = [&](int cls, uint32_t i) {
+        for (int c = 0; c < RT_NUM_CLASSES; ++c) {
+            bool mine = (cls == c);
+            if (__ballot(mine) == 0) continue;
+            uint32_t pos = block_append(mine, &s_cls[c]);
+            if (mine) cls_list[(size_t)c * cap + seg_base + pos] = i;
+        }
+    };
+    const ChunkLoop cl = block_chunks(total, 1);
+    uint32_t seg = cl.start < cl.end ? segment_of(s_prefix, cl.start) : 0;
+    for (uint32_t base = cl.start; base < cl.end; base += cl.stride) {
+        const uint32_t g = base + threadIdx.x;
+        const bool active = g < cl.end;
+        uint32_t i = 0;
+        F3 o = f3(0.f, 0.f, 0.f), d = f3(1.f, 1.f, 1.f);
+        if (active) {
+            while (g >= s_prefix[seg + 1]) seg++;
+            i = seg * segcap + (g - s_prefix[seg]);
+            o = f3(q.ox[i], q.oy[i], q.oz[i]); d = f3(q.dx[i], q.dy[i], q.dz[i]);
+        }
+        LaneTrav L;
+        lane_setup(L, o, d, RT_INF);
+        const bool run = active && L.plain;
+        bool replay = active && !L.plain;
+        // ---- every leaf box, the three nearest pierced ones kept as keys: entry distance (low five bits dropped) | leaf number
+        uint32_t k1 = ~0u, k2 = ~0u, k3 = ~0u;
+        for (int k = 0; k < n_flat; ++k) {
+            const float4 a = flat[2 * k], b = flat[2 * k + 1];
+            float tmin;
+            const bool ok = slab_fast(a.x, a.y, a.z, a.w, b.x, b.y, L.o, L.invDir, tmin) && tmin < RT_INF;      // geometry.h:913 with ray.tMax = Infinity
+            const uint32_t key = ok ? ((__float_as_uint(tmin > 0.f ? tmin : 0.f) & ~31u) | (uint32_t)k) : ~0u;
+            const uint32_t x = max(k1, key); k1 = min(k1, key);
+            const uint32_t y = max(k2, x); k2 = min(k2, x);
+            k3 = min(k3, y);
+        }
+        // ---- the primitives of the nearest leaf, then of the second nearest if it is still in reach
+        bool found = false;
+        float best_t = RT_INF, second = RT_INF, m_up = 0.f, hb0 = 0.f, hb1 = 0.f, hb2 = 0.f;
+        int hitSlot = -1;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t key = r == 0 ? k1 : k2;
+            const float bound = best_t * (1.f + RT_FLAT_CULL_BAND);
+            const bool go = run && key != ~0u && __uint_as_float(key & ~31u) < bound;
+            if (__ballot(go) == 0) continue;
+            LaneTrav E; E.cur = 0; E.count = 0;
+            if (go) lane_enter(sc, E, s_info[key & 31u], true);      // first slot and count of the leaf
+            const float entry_up = __uint_as_float(key | 31u);       // not below the box's entry distance
+            for (int j = 0; __ballot(go && j < E.count) != 0; ++j) {
+                if (!(go && j < E.count)) continue;
+                const int slot = E.cur + j;
+                const float4 r0 = s_slots[3 * slot], r1 = s_slots[3 * slot + 1], r2 = s_slots[3 * slot + 2];
+                const uint32_t flags = __float_as_uint(r2.y);
+                float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+                bool ok;
+                if (flags & RT_SLOT_SPHERE) ok = sphere_test(sc.spheres + 32 * (size_t)__float_as_int(r2.w), L.o, L.d, bound, t);
+                else ok = triangle_test_sheared(f3(r0.x, r0.y, r0.z), f3(r0.w, r1.x, r1.y), f3(r1.z, r1.w, r2.x), L.o, L.shear, bound, t, b0, b1, b2) &&
+                          !(flags & RT_SLOT_REJECT_CLOSEST);
+                if (ok) {
+                    if (!found || t < best_t) { second = best_t; best_t = t; hitSlot = slot; hb0 = b0; hb1 = b1; hb2 = b2; m_up = entry_up; found = true; }
+                    else second = fminf(second, t);
+                }
+            }
+        }
+        const float reach = best_t * (1.f + RT_FLAT_CULL_BAND);
+        const bool third = run && k3 != ~0u && __uint_as_float(k3 & ~31u) < reach;
+        const bool tie = run && found && (second <= fmaxf(best_t, m_up) * (1.f + RT_FLAT_TIE_BAND) || m_up > best_t * (1.f + 0.5f * RT_FLAT_CULL_BAND));
+        replay = replay || third || tie;
+        {
+            const uint32_t pos = block_append(replay, &s_replay);
+            if (replay) replay_list[pos] = i;
+        }
+        int cls = -1;
+        if (active && !replay) cls = hand_in(i, found, hitSlot, found ? best_t : RT_INF, hb0, hb1, hb2, d);
+        bin(cls, i);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- the replay list, in the reference's order
+    const uint32_t n_replay = s_replay;
+    for (uint32_t base = 0; base < n_replay; base += RT_BLOCK) {
+        const uint32_t j = base + threadIdx.x;
+        int cls = -1;
+        uint32_t i = 0;
+        if (j < n_replay) {
+            i = replay_list[j];
+            const F3 o = f3(q.ox[i], q.oy[i], q.oz[i]), d = f3(q.dx[i], q.dy[i], q.dz[i]);
+            LaneTrav L = {};
+            trace_one<false, RT_LDS_SCENE_NODES / 2>(sc, s_nodes, s_slots, o, d, RT_INF, pst, L);
+            cls = hand_in(i, L.found, L.hitSlot, L.tmax, L.b0, L.b1, L.b2, d);
+        }
+        bin(cls, i);
+    }
+    __syncthreads();
+    if (threadIdx.x < RT_NUM_CLASSES) bc->cls[threadIdx.x][blockIdx.x] = s_cls[threadIdx.x];
+    if (threadIdx.x == 0 && n_replay) atomicAdd(&stats[bounce].n_replay, n_replay);      // statistics only
 }
 
 // ------------------------------------------------------------------- shade --
@@ -1843,7 +2025,7 @@ struct rt_scene {
     std::vector<rt_bvh_node> nodes; std::vector<int32_t> order;
     int n_prims = 0;
     bool classes[RT_NUM_CLASSES] = {};
-    DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_envs, d_light_cdf, d_spill, d_pairs, d_quads;
+    DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_envs, d_light_cdf, d_spill, d_pairs, d_quads, d_flat;
     int interior_depth = 0;
     std::vector<DevBuf *> d_texels;
     DevBuf d_trace_io, d_work;
@@ -2238,6 +2420,32 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
             memcpy(Q + 24, info, 16); memcpy(Q + 28, &meta, 4);
         }
     }
+    // Is every interior box bit for bit the union of its children's (std::min / std::max argument order, geometry.h:833-840)?  True of
+    // every tree rt_bvh_build makes; a caller's tree may differ.  The root alone decides whether a walk may skip the root's own slab
+    // test; the whole tree decides whether "a leaf is reached exactly when its own box is hit" holds (k_extend_flat).
+    auto is_union = [&](int i) {
+        const rt_bvh_node &c = sc->nodes[i], &a = sc->nodes[i + 1], &b = sc->nodes[c.offset];
+        float u[6];
+        for (int j = 0; j < 3; ++j) { u[j] = b.bmin[j] < a.bmin[j] ? b.bmin[j] : a.bmin[j]; u[3 + j] = a.bmax[j] < b.bmax[j] ? b.bmax[j] : a.bmax[j]; }
+        return memcmp(u, c.bmin, 12) == 0 && memcmp(u + 3, c.bmax, 12) == 0;
+    };
+    bool nest_ok = true;
+    int n_leaves = 0;
+    for (int i = 0; i < nn; ++i) { if (sc->nodes[i].nprim != 0) n_leaves++; else if (!is_union(i)) nest_ok = false; }
+    const bool root_implied = sc->nodes[0].nprim == 0 && is_union(0);
+    // flat leaf table (k_extend_flat): the leaves' own boxes and info words, depth-first
+    std::vector<float> flat;
+    if (nest_ok && n_leaves <= RT_FLAT_MAX && !env_int("RT_AMD_NO_FLAT_TABLE", 0)) {
+        for (int i = 0; i < nn; ++i) {
+            const rt_bvh_node &nd = sc->nodes[i];
+            if (nd.nprim == 0) continue;
+            float rec[8] = {nd.bmin[0], nd.bmin[1], nd.bmin[2], nd.bmax[0], nd.bmax[1], nd.bmax[2], 0.f, 0.f};
+            uint32_t info = childInfo(i);
+            memcpy(rec + 6, &info, 4);
+            flat.insert(flat.end(), rec, rec + 8);
+        }
+        HIP_OK(up(sc->d_flat, flat.data(), flat.size() * 4));
+    }
     if (env_int("RT_AMD_NO_QUADS", 0)) quads_ok = false;
     int quad_cap = 3 * (tree_depth / 2 + 1) + 2;      // at most three pushes per record on the path from the root
     if (quads_ok) HIP_OK(up(sc->d_quads, quads.data(), quads.size() * 4));
@@ -2254,6 +2462,8 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     memcpy(D.root_box, sc->nodes[0].bmin, 12); memcpy(D.root_box + 3, sc->nodes[0].bmax, 12);
     D.root_info = childInfo(0);
     D.quads = quads_ok ? (const float4 *)sc->d_quads.p : nullptr; D.n_quads = quads_ok ? n_quads : 0; D.quad_stack_cap = quad_cap;
+    D.root_implied = root_implied ? 1 : 0;
+    D.flat = flat.empty() ? nullptr : (const float4 *)sc->d_flat.p; D.n_flat = (int)(flat.size() / 8);
     *out = sc.release();
     return 0;
 }
@@ -2497,7 +2707,7 @@ static int lane_prepare(rt_scene *this_, RenderLane &ln, const rt_camera *cam, c
         hipError_t e = ln.d_q[0].alloc(12 * cap * 4);
         if (e == hipSuccess) e = ln.d_q[1].alloc(12 * cap * 4);
         if (e == hipSuccess) e = ln.d_hits.alloc(5 * cap * 4);
-        if (e == hipSuccess) e = ln.d_cls.alloc((size_t)RT_NUM_CLASSES * cap * 4);
+        if (e == hipSuccess) e = ln.d_cls.alloc((size_t)(RT_NUM_CLASSES + 1) * cap * 4);      // one list per class + k_extend_flat's replay list
         if (e == hipSuccess) e = ln.d_shadow.alloc(10 * cap * 4);
         if (e == hipSuccess) e = ln.d_lbuf.alloc(cap * 16);
         if (e == hipSuccess) { ln.ws_cap = cap; break; }
@@ -2585,6 +2795,9 @@ static int render_lane(rt_scene *this_, RenderLane &ln, const rt_camera *cam, co
     rp.merge_mirror = (this_->classes[RT_MAT_MATTE] && this_->classes[RT_MAT_MIRROR]) ? std::max(0, std::min(2, env_int("RT_AMD_MERGE_MIRROR", 2))) : 0;
     // incoherent bounces of LDS scenes: lanes carry long rays over and refill (k_extend_carry); camera rays stay round-based
     const int carry_from = env_int("RT_AMD_CARRY_FROM", 1);
+    // incoherent bounces of LDS scenes with few leaves: no walk, every leaf box tested in lockstep (k_extend_flat)
+    const bool use_flat = lds_scene && round_pairs && !frame_old && this_->dev.flat != nullptr && env_int("RT_AMD_FLAT", 1) != 0;
+    const int flat_from = env_int("RT_AMD_FLAT_FROM", 1);
     // shadow rays traced inside the shading kernels: scenes whose tree and tables both sit in LDS
     // (only while five blocks of the fused kernel still share a CU's 160 KB of LDS: 25.6 KB static + the scene's tables <= 32 KB)
     const bool all_in_lds = lds_scene && round_pairs && !frame_old && shade_tables_in_lds(this_->dev) && shade_lds_bytes(this_->dev) <= 6400 && !this_->dev.envs;
@@ -2620,7 +2833,10 @@ static int render_lane(rt_scene *this_, RenderLane &ln, const rt_camera *cam, co
                 tm.mark(RT_TIME_OTHER);
                 break;
             }
-            if (frame_old || b < round_bounces) {
+            if (use_flat && b >= flat_from)
+                hipLaunchKernelGGL(k_extend_flat, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)ln.d_cls.p,
+                                   ucap, useg, lbuf, counts, bstats, this_->dev.flat, this_->dev.n_flat);
+            else if (frame_old || b < round_bounces) {
                 if (lds_scene && round_pairs && b >= carry_from)
                     hipLaunchKernelGGL(k_extend_carry, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)ln.d_cls.p,
                                        ucap, useg, lbuf, counts, bstats);
@@ -2692,7 +2908,7 @@ static int render_lane(rt_scene *this_, RenderLane &ln, const rt_camera *cam, co
         HIP_OK(hipStreamSynchronize(ln.stream));
         tm.end_pass();
         st.samples += rp.n_paths;
-        for (size_t b = 0; b < n_bounce; ++b) { st.rays_closest += hs[b].n_queue; st.rays_shadow += hs[b].n_shadow; if (hs[b].n_queue) st.iterations++; }
+        for (size_t b = 0; b < n_bounce; ++b) { st.rays_closest += hs[b].n_queue; st.rays_shadow += hs[b].n_shadow; st.rays_replayed += hs[b].n_replay; if (hs[b].n_queue) st.iterations++; }
         if (use_finish && finish_at == 1 << 30 && rp.n_paths >= 4096) {       // a pass through every bounce: note how fast the paths die out
             ln.survival.assign((size_t)o->max_depth + 1, 0.f);
             for (int b = 0; b <= o->max_depth; ++b) ln.survival[b] = (float)((double)hs[b].n_queue / rp.n_paths);
@@ -2792,7 +3008,7 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
     HIP_OK(hipEventElapsedTime(&ms, ev.a, ev.b));
     rt_render_stats st = ls[0];
     for (int k = 1; k < n_lanes; ++k) {
-        st.samples += ls[k].samples; st.rays_closest += ls[k].rays_closest; st.rays_shadow += ls[k].rays_shadow; st.iterations += ls[k].iterations;
+        st.samples += ls[k].samples; st.rays_closest += ls[k].rays_closest; st.rays_shadow += ls[k].rays_shadow; st.iterations += ls[k].iterations; st.rays_replayed += ls[k].rays_replayed;
     }
     st.seconds_total = (double)ms * 1e-3;
     if (stats) *stats = st;
@@ -2900,7 +3116,7 @@ int rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_opts *opt
     if (stats_total) {
         rt_render_stats t; memset(&t, 0, sizeof(t));
         for (int i = 0; i < n; ++i) {
-            t.samples += st[i].samples; t.rays_closest += st[i].rays_closest; t.rays_shadow += st[i].rays_shadow; t.iterations += st[i].iterations;
+            t.samples += st[i].samples; t.rays_closest += st[i].rays_closest; t.rays_shadow += st[i].rays_shadow; t.iterations += st[i].iterations; t.rays_replayed += st[i].rays_replayed;
             t.seconds_total = std::max(t.seconds_total, st[i].seconds_total);      // the devices ran side by side
             t.seconds_trace += st[i].seconds_trace; t.seconds_shade += st[i].seconds_shade; t.seconds_shadow += st[i].seconds_shadow; t.seconds_other += st[i].seconds_other;
         }

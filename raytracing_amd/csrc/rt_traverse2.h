@@ -166,7 +166,9 @@ __device__ __forceinline__ void lane_setup(LaneTrav &L, F3 o, F3 d, float tmax) 
 // For a plain ray and an interior root the test is left out: whatever the walk does next is decided by the boxes of the root's
 // children (pair records) or grandchildren (quad records), and one of those can only pass if the root's box — their exact
 // componentwise union, under monotonic slab arithmetic — passes too, tMin < tMax included; a ray that misses the root then ends
-// after one step instead of none, with the same result.  (The counting variant keeps the test: it counts the reference's slab tests.)
+// after one step instead of none, with the same result.  A tree handed in by the caller may carry a root box that is not that
+// union (a tighter one, say): sc.root_implied says whether it is, and without it the test is made.  (The counting variant keeps
+// the test: it counts the reference's slab tests.)
 template <bool COUNT, class Stack>
 __device__ __forceinline__ bool lane_begin(const DevScene &sc, LaneTrav &L, Stack &st, F3 o, F3 d, float tmax, uint32_t &nNodes) {
     lane_setup(L, o, d, tmax);
@@ -174,7 +176,7 @@ __device__ __forceinline__ bool lane_begin(const DevScene &sc, LaneTrav &L, Stac
     bool have = false;
     if (sc.n_nodes != 0) {
         if (COUNT) nNodes++;
-        if (!COUNT && L.plain && (sc.root_info & RT_PAIR_LEAF) == 0) have = true;
+        if (!COUNT && L.plain && sc.root_implied && (sc.root_info & RT_PAIR_LEAF) == 0) have = true;
         else {
             float tMin;
             have = slab_partial(sc.root_box[0], sc.root_box[1], sc.root_box[2], sc.root_box[3], sc.root_box[4], sc.root_box[5], o, L.invDir, L.negx, L.negy, L.negz, tMin) &&
@@ -469,7 +471,7 @@ __device__ __forceinline__ void any_walk_begin(const DevScene &sc, LaneTrav &L, 
     st.reset();
     A.has_cur = false; A.nl = 0; A.slot = 0; A.left = 0; A.found = false; A.cur = sc.root_info;
     if (sc.n_nodes != 0) {
-        if (L.plain && (sc.root_info & RT_PAIR_LEAF) == 0) A.has_cur = true;
+        if (L.plain && sc.root_implied && (sc.root_info & RT_PAIR_LEAF) == 0) A.has_cur = true;
         else {
             float tMin;
             A.has_cur = slab_partial(sc.root_box[0], sc.root_box[1], sc.root_box[2], sc.root_box[3], sc.root_box[4], sc.root_box[5], o, L.invDir, L.negx, L.negy, L.negz, tMin) &&

@@ -381,7 +381,10 @@ def test_frame_walks_give_identical_images(name, w, device_scene, host_scene, mo
                 {"RT_AMD_FINISH": "0"},
                 # fused shading kernels: every wave walks the shadow rays of its own 64 paths at once instead of collecting full waves of them
                 {"RT_AMD_PACK_SHADOW": "0"}, {"RT_AMD_PACK_SHADOW": "0", "RT_AMD_FINISH": "0"},
-                {"RT_AMD_FUSE_SHADOW": "0", "RT_AMD_CARRY_FROM": "1000", "RT_AMD_MERGE_MIRROR": "0", "RT_AMD_FRAME_BLOCKS_PER_CU": "4"})
+                {"RT_AMD_FUSE_SHADOW": "0", "RT_AMD_CARRY_FROM": "1000", "RT_AMD_MERGE_MIRROR": "0", "RT_AMD_FRAME_BLOCKS_PER_CU": "4"},
+                # closest hits of the bounce rays by the ordered walk (k_extend_carry) instead of the order-free leaf-box test with replay
+                # (k_extend_flat, trees of at most 32 leaves), and the order-free test for the camera rays too
+                {"RT_AMD_FLAT": "0"}, {"RT_AMD_FLAT_FROM": "0"}, {"RT_AMD_FLAT": "0", "RT_AMD_FINISH": "0"})
     for env in variants:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -408,6 +411,30 @@ def test_deferred_shadow_walks_answer_as_the_ordered_walks(name, w, ordered, dev
         monkeypatch.setenv(k, v)
     img, st2 = ds.render(cam, opts)
     assert st.rays_shadow > 0 and (st2.rays_closest, st2.rays_shadow) == (st.rays_closest, st.rays_shadow)
+    assert np.array_equal(img, base)
+
+
+@pytest.mark.parametrize("name,w", [("cornell", 800), ("cornell_plastic", 500), ("cornell_metal", 500), ("cornell_roughglass", 500)])
+def test_order_free_closest_hits_answer_as_the_ordered_walk(name, w, device_scene, host_scene, monkeypatch):
+    """Bounce rays of trees with at most 32 leaves find their closest hit without a walk (k_extend_flat: every leaf box, nearest two
+    leaves, near-ties and everything else inconclusive replayed in the reference's order).  Against the ordered walk of
+    k_extend_carry on millions of paths: one differing hit would change a radiance sum, so the images must be identical to the last
+    bit and the ray counts equal; the replayed share is small."""
+    ds = device_scene(name)
+    cam = host_scene(name).camera(w, w)
+    opts = ra.make_opts(4, 4)
+    monkeypatch.setenv("RT_AMD_RENDER_LANES", "1")
+    monkeypatch.setenv("RT_AMD_FINISH", "0")
+    base, st = ds.render(cam, opts)
+    assert st.rays_replayed > 0 and st.rays_replayed < 0.12 * st.rays_closest, (st.rays_replayed, st.rays_closest)
+    monkeypatch.setenv("RT_AMD_FLAT", "0")
+    img, st2 = ds.render(cam, opts)
+    assert st2.rays_replayed == 0 and (st2.rays_closest, st2.rays_shadow) == (st.rays_closest, st.rays_shadow)
+    assert np.array_equal(img, base)
+    monkeypatch.setenv("RT_AMD_FLAT", "1")
+    monkeypatch.setenv("RT_AMD_FLAT_FROM", "0")
+    img, st3 = ds.render(cam, opts)
+    assert (st3.rays_closest, st3.rays_shadow) == (st.rays_closest, st.rays_shadow)
     assert np.array_equal(img, base)
 
 
