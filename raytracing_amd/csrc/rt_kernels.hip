@@ -90,6 +90,7 @@ struct RenderParams {
     float rr_threshold; // its rrThreshold
     int nee_mode;       // 0: UniformSampleOneLight and BSDF sampling in one launch; UniformSampleAllLights (integrator.cpp:26-51) takes one launch per
     int nee_light;      // light with nee_mode 1 (direct light of light nee_light only) and a last one with nee_mode 2 (BSDF sampling only)
+    uint32_t class_mask; // bit c: the scene has a material of class c (the binning loops skip the others without a ballot)
 };
 
 // ---------------------------------------------------------------- helpers --
@@ -456,6 +457,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend(DevScene sc, RenderParam
         }
         // bin the path into the queue of its material class (one ballot per class present in the wave)
         for (int c = 0; c < RT_NUM_CLASSES; ++c) {
+            if (!((rp.class_mask >> c) & 1u)) continue;
             bool mine = (cls == c);
             if (__ballot(mine) == 0) continue;
             uint32_t pos = block_append(mine, &s_cls[c]);
@@ -542,6 +544,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_carry(DevScene sc, RenderPa
         }
         if (__ballot(fin) != 0)
             for (int c = 0; c < RT_NUM_CLASSES; ++c) {
+                if (!((rp.class_mask >> c) & 1u)) continue;
                 bool mine = (cls == c);
                 if (__ballot(mine) == 0) continue;
                 uint32_t pos = block_append(mine, &s_cls[c]);
@@ -608,6 +611,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_carry(DevScene sc, RenderPa
 //   * What the bands assume: no primitive's computed hit distance lies below the entry distance of its own leaf's box (or of an
 //     enclosing box) by more than the difference of the two bands, 0.1 % — a leaf skipped here cannot then hold a hit that the
 //     reference, arriving there with a larger tMax, would have accepted below the best t found here.
+typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef RT_FLAT_CULL_BAND
 #define RT_FLAT_CULL_BAND 1e-3f
 #endif
@@ -668,6 +672,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend_flat(DevScene sc, Render
     };
     auto bin = [&](int cls, uint32_t i) {
         for (int c = 0; c < RT_NUM_CLASSES; ++c) {
+            if (!((rp.class_mask >> c) & 1u)) continue;
             bool mine = (cls == c);
             if (__ballot(mine) == 0) continue;
             uint32_t pos = block_append(mine, &s_cls[c]);
@@ -691,12 +696,23 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend_flat(DevScene sc, Render
         const bool run = active && L.plain;
         bool replay = active && !L.plain;
         // ---- every leaf box, the three nearest pierced ones kept as keys: entry distance (low five bits dropped) | leaf number
+        // (slab_fast on two-float vectors, which compile to packed subtractions and multiplications — the same IEEE operations on the
+        // same numbers: the record's three pairs (min x, min y), (min z, max x), (max y, max z) against the ray's origin and reciprocal
+        // direction laid out to match.  max(tMin, smallest positive number) <= tMax is  tMin <= tMax && tMax > 0  in one comparison
+        // (denormals are kept), and that maximum, never negative, is also what the key needs.  An entry distance of +Infinity (an
+        // overflowing product) makes a key like any other; the comparisons against the reach below then keep the leaf out, as
+        // tMin < ray.tMax does in the reference, geometry.h:913.)
+        const v2f oA = {L.o.x, L.o.y}, oB = {L.o.z, L.o.x}, oC = {L.o.y, L.o.z};
+        const v2f iA = {L.invDir.x, L.invDir.y}, iB = {L.invDir.z, L.invDir.x}, iC = {L.invDir.y, L.invDir.z};
         uint32_t k1 = ~0u, k2 = ~0u, k3 = ~0u;
         for (int k = 0; k < n_flat; ++k) {
             const float4 a = flat[2 * k], b = flat[2 * k + 1];
-            float tmin;
-            const bool ok = slab_fast(a.x, a.y, a.z, a.w, b.x, b.y, L.o, L.invDir, tmin) && tmin < RT_INF;      // geometry.h:913 with ray.tMax = Infinity
-            const uint32_t key = ok ? ((__float_as_uint(tmin > 0.f ? tmin : 0.f) & ~31u) | (uint32_t)k) : ~0u;
+            const v2f P0 = {a.x, a.y}, P1 = {a.z, a.w}, P2 = {b.x, b.y};
+            const v2f T0 = (P0 - oA) * iA, T1 = (P1 - oB) * iB, T2 = (P2 - oC) * iC;      // (x0, y0), (z0, x1), (y1, z1)
+            const float widen = 1 + 2 * ((3 * 5.9604644775390625e-08f) / (1 - 3 * 5.9604644775390625e-08f));
+            const float nx = fminf(T0.x, T1.y), fx = fmaxf(T0.x, T1.y), ny = fminf(T0.y, T2.x), fy = fmaxf(T0.y, T2.x), nz = fminf(T1.x, T2.y), fz = fmaxf(T1.x, T2.y);
+            const float tMin = fmaxf(fmaxf(fmaxf(nx, ny), nz), __uint_as_float(1u)), tMax = fminf(fminf(fx, fy), fz) * widen;
+            const uint32_t key = tMin <= tMax ? ((__float_as_uint(tMin) & ~31u) | (uint32_t)k) : ~0u;
             const uint32_t x = max(k1, key); k1 = min(k1, key);
             const uint32_t y = max(k2, x); k2 = min(k2, x);
             k3 = min(k3, y);
@@ -1882,6 +1898,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend_pl(DevScene sc, RenderPa
             if (!terminal) { cls = sc.materials[sc.slot_material[slot]].kind; if (rp.merge_mirror == 1 && cls == RT_MAT_MIRROR) cls = RT_MAT_MATTE; }
         }
         for (int c = 0; c < RT_NUM_CLASSES; ++c) {
+            if (!((rp.class_mask >> c) & 1u)) continue;
             bool mine = (cls == c);
             if (__ballot(mine) == 0) continue;
             uint32_t pos = block_append(mine, &s_cls[c]);
@@ -2762,6 +2779,7 @@ static int render_lane(rt_scene *this_, RenderLane &ln, const rt_camera *cam, co
     rp.d_nstrata = make_fastdiv((uint32_t)(o->strata_x * o->strata_y));
     // the estimators next to Li_re run through the general shading kernels: no fused shadow rays, no k_finish
     rp.li = (o->flags & RT_RENDER_LI) ? 1 : 0; rp.rr_threshold = o->rr_threshold;
+    for (int c = 0; c < RT_NUM_CLASSES; ++c) if (this_->classes[c]) rp.class_mask |= 1u << c;
     const bool all_lights = (o->flags & RT_RENDER_ALL_LIGHTS) != 0 && this_->dev.n_lights > 0;
     const bool general = rp.li || all_lights;
 
