@@ -225,6 +225,13 @@ def cpu_baseline(scene, name, W, H):
     return out
 
 
+def lib_sha16():
+    """First 16 hex digits of the sha-256 of the HIP library that is loaded (what tests/pmc_frame_json.py stamps its summaries with)."""
+    import hashlib
+    p = os.path.join(ROOT, "raytracing_amd", "lib", "librt_amd.so")
+    return hashlib.sha256(open(p, "rb").read()).hexdigest()[:16] if os.path.exists(p) else None
+
+
 def frame_roofline(ds, cam, sx, sy, name, W, H, n_paths_per_s, stats):
     """What bounds the frame.  Scenes that fit LDS (Cornell) are bound by VALU issue: the fraction reported is the share of the
     chip's VALU lane-slots that did useful work = VALU busy x lane utilisation, both from the PMC summary of the same frame
@@ -240,29 +247,42 @@ def frame_roofline(ds, cam, sx, sy, name, W, H, n_paths_per_s, stats):
                     "shadow": "any-hit kernels", "other": "ray generation, late-bounce kernel, accumulation"},
            "grays_per_s": round((stats["rays_closest"] + stats["rays_shadow"]) / stats["seconds"] / 1e9, 3),
            "rays_per_sample": round((stats["rays_closest"] + stats["rays_shadow"]) / max(1, stats["samples"]), 3)}
-    pmc = None
+    pmc = None; stale = None
+    sha = lib_sha16()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_frame_pmc_%s.json" % name))):
         try:
             rec = json.load(open(f))
             if rec.get("scene") == name and rec.get("width") == W and rec.get("height") == H:
-                pmc = rec; pmc_src = os.path.relpath(f, ROOT)
+                if rec.get("lib_sha16") == sha:
+                    pmc = rec; pmc_src = os.path.relpath(f, ROOT)
+                else:
+                    stale = os.path.relpath(f, ROOT)
         except Exception:
             pass
     if pmc:
-        # The counters (and the per-class times above) come from runs in which the launches are serialised: rocprofv3 runs one dispatch at
-        # a time while it counts, and the events of RT_RENDER_TIME_KERNELS keep the render on one lane.  The timed frame overlaps two or three lanes,
-        # each on its own stream; it issues the same instructions in less time, so its share of useful lane-slots is the serialised share times
-        # (serialised frame time / timed frame time).
+        # DERIVED, not counted in this run.  The counters come from a run in which the launches are serialised (rocprofv3 counts one dispatch at
+        # a time) over a sample of the frame's spp; the timed frame overlaps two or three lanes, each on its own stream: it issues the same
+        # instructions in less time, so its share of useful lane-slots is the serialised share times (serialised kernel time / timed frame
+        # time).  The serialised time is the sum of the dispatch durations of the PMC run itself, scaled from its spp to the frame's; where
+        # the counter file has no timestamps, the event-bracketed sum measured above stands in (slightly larger: it includes launch gaps).
+        # Quoted only when the PMC summary was made with the very library that is running (sha-256 of librt_amd.so).
         serial = pmc["frame"]["useful_lane_fraction"]
-        overlap = tot / stats["seconds"] if stats["seconds"] > 0 else 1.0
-        out.update({"achieved": round(serial * overlap, 4), "peak": 1.0, "unit": "fraction of VALU lane-slots doing useful work",
-                    "frac": round(serial * overlap, 4), "serialised": {"useful_lane_fraction": serial, "valu_busy": pmc["frame"]["valu_busy"],
-                                                                     "lane_utilisation": pmc["frame"]["lane_utilisation"], "frame_seconds": round(tot, 5)},
+        ser_s = pmc.get("serial_kernel_seconds")
+        if ser_s and pmc.get("sample_spp"):
+            ser_s = ser_s * (sx * sy) / pmc["sample_spp"]; ser_src = "sum of the PMC run's dispatch durations, scaled to the frame's spp"
+        else:
+            ser_s = tot; ser_src = "HIP events around every launch of one extra frame (includes launch gaps)"
+        overlap = ser_s / stats["seconds"] if stats["seconds"] > 0 else 1.0
+        frac = min(1.0, serial * overlap)
+        out.update({"achieved": round(frac, 4), "peak": 1.0, "unit": "fraction of VALU lane-slots doing useful work", "frac": round(frac, 4), "derived": True,
+                    "serialised": {"useful_lane_fraction": serial, "valu_busy": pmc["frame"]["valu_busy"],
+                                   "lane_utilisation": pmc["frame"]["lane_utilisation"], "frame_seconds": round(ser_s, 5), "frame_seconds_from": ser_src},
                     "timed_frame_seconds": round(stats["seconds"], 5), "overlap_factor": round(overlap, 4),
-                    "derivation": "frac = serialised.useful_lane_fraction (PMC, one dispatch at a time) x serialised.frame_seconds / timed_frame_seconds (render lanes overlapped)",
-                    "per_kernel": pmc["kernels"], "pmc_source": pmc_src, "pmc_sample": pmc.get("sample")})
+                    "derivation": "frac = serialised.useful_lane_fraction (PMC, one dispatch at a time) x serialised.frame_seconds / timed_frame_seconds (render lanes overlapped), capped at 1",
+                    "per_kernel": pmc["kernels"], "pmc_source": pmc_src, "pmc_sample": pmc.get("sample"), "lib_sha16": sha})
     else:
-        out.update({"achieved": None, "peak": 1.0, "unit": "fraction of VALU lane-slots doing useful work", "frac": None})
+        out.update({"achieved": None, "peak": 1.0, "unit": "fraction of VALU lane-slots doing useful work", "frac": None,
+                    "why_null": ("the PMC summary %s was made with another build of librt_amd.so" % stale) if stale else "no PMC summary of this frame under profiles/"})
     return out
 
 
@@ -350,18 +370,28 @@ def main():
     cam = scene.camera(W, H)
     frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
 
+    timings = {}
+
     def step():
-        return render_frame_split(ds, cam, SX, SY, MAX_DEPTH, rank, world, frame, dist)
+        return render_frame_split(ds, cam, SX, SY, MAX_DEPTH, rank, world, frame, dist, timings=timings if world > 1 else None)
 
     for _ in range(args.warmup):
         step()
     fence()
+    timings.clear()
     t0 = time.perf_counter()
     stats = None
     for _ in range(args.steps):
         stats = step()
     fence()
     dt = reduce_max(time.perf_counter() - t0)
+    # several ranks: where a frame's time goes — every rank's own render (mean over the steps) and the copy + reduce that follows it
+    per_rank = None
+    if world > 1:
+        slots = [0.0] * (2 * world)      # (an all-reduce of a vector with this rank's slots filled in: works on every backend)
+        slots[2 * rank] = sum(timings["render_ms"]) / len(timings["render_ms"]); slots[2 * rank + 1] = sum(timings["reduce_ms"]) / len(timings["reduce_ms"])
+        slots = reduce_sum(slots)
+        per_rank = [[round(slots[2 * r], 3), round(slots[2 * r + 1], 3)] for r in range(world)]
     # per-frame counters of the last step, summed over the ranks (each rank traced its own share of the samples)
     s_samples, s_closest, s_shadow = reduce_sum([stats.samples, stats.rays_closest, stats.rays_shadow]) if stats else (0, 0, 0)
 
@@ -380,6 +410,13 @@ def main():
             "mrays_per_s": round((s_closest + s_shadow) * args.steps / dt / 1e6, 1),
             "image_mean_rgb": [round(float(v), 5) for v in img.mean(axis=(0, 1))],
         }
+        if per_rank:
+            r_ms = [p[0] for p in per_rank]
+            out["render_ms_per_rank"] = {"max": max(r_ms), "min": min(r_ms), "all": r_ms,
+                                         "what": "wall clock of each rank's own rt_render_device call (its share of the samples), mean over the timed steps"}
+            out["reduce_ms"] = {"rank0": per_rank[0][1], "min_over_ranks": min(p[1] for p in per_rank),
+                                "what": "copy of the rank's sums into the frame tensor + the one reduce, until the device is idle again; a rank that "
+                                        "finished its render early waits here for the others, so the smallest value is the cost of the reduce itself"}
         if world == 1:
             try:
                 out["roofline_frame"] = frame_roofline(ds, cam, SX, SY, args.scene, W, H, out["value"] * 1e6,

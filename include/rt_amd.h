@@ -279,14 +279,18 @@ int rt_trace_closest_device(rt_scene *scene, size_t n, const void *rays, void *h
                             int repeats, int count_work, rt_trace_stats *stats);
 
 /* rt_trace_closest_device (count_work / stats as there, one launch, same rays / hits layout, synchronous) for callers that
- * cannot allocate device memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has
- * no counterpart in the reference.  The call allocates nothing: the traversal stacks' spill area and the work counters, which
- * the other entry points keep in buffers the library allocates, live in a static array of 32 MiB + 256 bytes in device memory
- * that every GPU the library runs on holds until the process ends (its address is taken once per context, in rt_init).  The
- * kernels and their results are those of rt_trace_closest_device; only the grid is cut down to the lanes whose stacks fit the
- * array (never below 256 blocks).  Limits, refused with an error: n > 2^28 rays; count_work without stats.  All calls on one
- * GPU share that GPU's array, so calls that overlap on one GPU (two contexts on the same device, from two threads) race; the
- * array keeps the last call's contents, and the call clears the part that must start at zero (the counters). */
+ * cannot allocate device memory: tight serving loops, harnesses that forbid hipMalloc, set-up phases of code that later runs under
+ * HIP graph capture.  (The call itself launches on the library's own stream and waits for the result, so it cannot be captured
+ * into a graph as it stands.)  It has no counterpart in the reference.  The call allocates nothing: the traversal stacks' spill area
+ * and the work counters, which the other entry points keep in buffers the library allocates, live in a static array of 32 MiB +
+ * 256 bytes in device memory that every GPU the library runs on holds until the process ends (its address is taken once per
+ * context, in rt_init).  The kernels and their results are those of rt_trace_closest_device; only the grid is cut down to the
+ * blocks whose lanes' stacks fit the array: 32 MiB / (256 lanes x 8 bytes x max(64, 3 * (interior levels / 2 + 1) + 2) entries),
+ * i.e. 256 blocks for trees of up to 40 interior levels and 162 at the 64 levels rt_scene_create accepts.  The two HIP events that
+ * time the launch belong to the context and are shared by its scenes.  Limits, refused with an error: n > 2^28 rays; count_work
+ * without stats.  All calls on one GPU share that GPU's array, so calls that overlap on one GPU (two contexts on the same device,
+ * from two threads) race; the array keeps the last call's contents, and the call clears the part that must start at zero (the
+ * counters). */
 int rt_trace_closest_device_noalloc(rt_scene *scene, size_t n, const void *rays, void *hits, int count_work, rt_trace_stats *stats);
 
 /* Render samples [sample_begin, sample_end) of every pixel and return the
@@ -317,7 +321,8 @@ int rt_multi_create(const int32_t *devices, int32_t n_devices, const rt_scene_de
 void rt_multi_destroy(rt_multi *m);
 const char *rt_multi_last_error(rt_multi *m);               /* m may be NULL for rt_multi_create failures */
 /* rt_render over all devices of m: out_sum_rgb as in rt_render; stats_per_device (n_devices records) and stats_total
- * (counts summed, seconds_total = slowest device) may be NULL. */
+ * (counts summed, seconds_total = slowest device) may be NULL.  RT_RENDER_ACCUMULATE is refused with an error: every call
+ * merges fresh per-device sums (add frames on the host, or use rt_render_device per device, to accumulate). */
 int rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_opts *opts, float *out_sum_rgb,
                     rt_render_stats *stats_per_device, rt_render_stats *stats_total);
 

@@ -2595,7 +2595,7 @@ int rt_trace_closest_device(rt_scene *this_, size_t n, const void *rays, void *h
 
 // rt_trace_closest_device for callers that cannot allocate: the spill area of the traversal stacks and the work counters live
 // in this device's copy of the static `scratch` array instead of buffers the library allocates.  The grid is cut down until its
-// lanes' stacks fit the spill area (32 MiB): at least 256 blocks for any tree rt_scene_create accepts.
+// lanes' stacks fit the spill area (32 MiB): 256 blocks while a lane needs at most 64 entries, 162 for the deepest tree rt_scene_create accepts.
 int rt_trace_closest_device_noalloc(rt_scene *this_, size_t n, const void *rays, void *hits, int count_work, rt_trace_stats *stats) {
     if (!this_ || !rays || !hits || n == 0) return -1;
     rt_ctx *ctx = this_->ctx;
@@ -3099,6 +3099,7 @@ int rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_opts *opt
     const int n = (int)m->ctx.size();
     const int32_t total = opts->sample_end - opts->sample_begin;
     if (total < 0) { m->error = "rt_multi_render: empty or reversed sample range"; return -1; }
+    if (opts->flags & RT_RENDER_ACCUMULATE) { m->error = "rt_multi_render: RT_RENDER_ACCUMULATE is not supported (every call merges fresh per-device sums)"; return -1; }
     std::vector<int> rc(n, 0);
     std::vector<void *> dsum(n, nullptr);
     std::vector<rt_render_stats> st(n);
@@ -3109,7 +3110,6 @@ int rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_opts *opt
             int32_t b = 0, e = 0;
             rt_split_samples(total, i, n, &b, &e);
             o.sample_begin = opts->sample_begin + b; o.sample_end = opts->sample_begin + e;
-            o.flags &= ~RT_RENDER_ACCUMULATE;
             memset(&st[i], 0, sizeof(st[i]));
             rc[i] = rt_render_device(m->scene[i], cam, &o, &dsum[i], &st[i]);
         });

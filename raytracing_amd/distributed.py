@@ -25,17 +25,27 @@ def reduce_frame(frame, dist, dst=0):
     return frame
 
 
-def render_frame_split(scene, cam, sx, sy, max_depth, rank, world, frame, dist, seed=(0x243F6A88, 0x85A308D3)):
+def render_frame_split(scene, cam, sx, sy, max_depth, rank, world, frame, dist, seed=(0x243F6A88, 0x85A308D3), timings=None):
     """Render this rank's share of the sx*sy samples into `frame` (torch tensor H x W x 3 on the rank's device) and reduce.
-    Returns the rank's rt_render_stats."""
+    Returns the rank's rt_render_stats.  timings (a dict of lists, optional) receives this step's wall-clock milliseconds of the
+    rank's render ("render_ms": rt_render_device returns when the share is rendered) and of the copy + reduce ("reduce_ms",
+    which includes waiting for slower ranks); measuring the second costs one device synchronisation per step."""
+    import time
     import torch
     begin, end = split_samples(sx * sy, rank, world)
+    t0 = time.perf_counter()
     ptr, stats = scene.render_device(cam, make_opts(sx, sy, begin=begin, end=end, max_depth=max_depth, seed=seed))
+    t1 = time.perf_counter()
     n = cam.width * cam.height * 3
     # wrap the library-owned device buffer without copying through the host
     src = _as_tensor(ptr, n, frame.device)
     frame.view(-1).copy_(src)
     reduce_frame(frame, dist)
+    if timings is not None:
+        if getattr(frame, "is_cuda", False):
+            torch.cuda.synchronize()
+        timings.setdefault("render_ms", []).append((t1 - t0) * 1e3)
+        timings.setdefault("reduce_ms", []).append((time.perf_counter() - t1) * 1e3)
     return stats
 
 

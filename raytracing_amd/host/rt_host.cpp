@@ -504,8 +504,15 @@ void PathIntegrator::Render(const Scene &scene, int image_width, int image_heigh
     o.flags = (estimateWithLi ? RT_RENDER_LI : 0) | (sampleAllLights ? RT_RENDER_ALL_LIGHTS : 0);
     lastSum.assign((size_t)image_width * image_height * 3, 0.f);
     // Every GPU the process sees takes a share of the samples of every pixel (RT_AMD_DEVICES=n caps the number); one GPU renders alone.
-    int nDev = rt_device_count();
-    if (const char *cap = getenv("RT_AMD_DEVICES")) { int c = atoi(cap); if (c >= 1 && c < nDev) nDev = c; }
+    // Under a one-process-per-GPU launcher (torchrun and its like export LOCAL_RANK / WORLD_SIZE) every rank would otherwise drive all
+    // GPUs at once, so such a process keeps to one device — its own, by LOCAL_RANK — unless RT_AMD_DEVICES says otherwise.
+    int nDev = rt_device_count(), firstDev = 0;
+    const bool launched = getenv("LOCAL_RANK") || getenv("WORLD_SIZE");
+    if (launched) {
+        if (const char *lr = getenv("LOCAL_RANK")) { int r = atoi(lr); if (r >= 0 && r < nDev) firstDev = r; }
+        nDev = nDev > 0 ? 1 : 0;
+    }
+    if (const char *cap = getenv("RT_AMD_DEVICES")) { int c = atoi(cap); if (c >= 1 && c <= rt_device_count()) { nDev = c; if (c > 1) firstDev = 0; } }
     if (nDev > 1) {
         std::vector<int32_t> devs(nDev);
         for (int i = 0; i < nDev; ++i) devs[i] = i;
@@ -517,7 +524,7 @@ void PathIntegrator::Render(const Scene &scene, int image_width, int image_heigh
         if (rc) throw std::runtime_error(err);
     } else {
         rt_ctx *ctx = nullptr;
-        if (rt_init(0, &ctx) != 0) throw std::runtime_error(std::string("rt_init: ") + rt_last_error(nullptr));
+        if (rt_init(firstDev, &ctx) != 0) throw std::runtime_error(std::string("rt_init: ") + rt_last_error(nullptr));
         rt_scene *sc = nullptr;
         if (rt_scene_create(ctx, &fs->desc, &sc) != 0) { std::string e = rt_last_error(ctx); rt_shutdown(ctx); throw std::runtime_error("rt_scene_create: " + e); }
         int rc = rt_render(sc, &cam, &o, lastSum.data(), &lastStats);

@@ -276,7 +276,7 @@ if __name__ == "__main__":
     if not only or "sphere1" in only:
         golden_for_scene("sphere1", 4096, [(64, 64, 4, 4, [A, B])])
     if not only or "spheres2" in only:
-        golden_for_scene("spheres2", 4096, [(96, 96, 8, 8, [A, B])])
+        golden_for_scene("spheres2", 4096, [(96, 96, 8, 8, [A, B]), (160, 90, 8, 8, [A, B])])      # 160 x 90: the 1440 x 810 frame's own aspect
     if not only or "helmet" in only:
         golden_for_scene("helmet", 4096, [(96, 96, 8, 8, [A, B])])
     print("fixtures written to", GOLD)
