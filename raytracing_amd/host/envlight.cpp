@@ -67,24 +67,33 @@ bool ReadHDR(const std::string &path, int *width, int *height, std::vector<float
     int w = 0, h = 0;
     if (sscanf(res.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0 || (size_t)w * h > ((size_t)1 << 28)) return false;
     std::vector<uint8_t> rgbe((size_t)w * h * 4);
-    for (int y = 0; y < h; ++y) {
+    // stbi__hdr_load: images narrower than 8 or wider than 32767 pixels are flat; otherwise every scanline starts with 2 2 and its
+    // length (high bit clear), which must equal the width ("invalid decoded scanline length" if not).  A first scanline without that
+    // header means the whole file is flat, its first four bytes being pixel 0; the same thing on a later scanline sends stb's loop back to
+    // pixel 1 of row 0 (its own comment: "this makes no sense") — such a file is refused here.
+    bool flat = w < 8 || w >= 32768;
+    for (int y = 0; y < h && !flat; ++y) {
         uint8_t *row = &rgbe[(size_t)y * w * 4];
-        bool rle = w >= 8 && w < 32768 && p + 4 <= d.size() && d[p] == 2 && d[p + 1] == 2 && !(d[p + 2] & 0x80);
-        if (rle && ((d[p + 2] << 8) | d[p + 3]) == w) {
-            p += 4;
-            for (int k = 0; k < 4; ++k) {
-                int i = 0;
-                while (i < w) {
-                    if (p >= d.size()) return false;
-                    int count = d[p++];
-                    if (count > 128) { count -= 128; if (p >= d.size() || i + count > w) return false; uint8_t v = d[p++]; for (int z = 0; z < count; ++z) row[4 * (i++) + k] = v; }
-                    else { if (count == 0 || p + count > d.size() || i + count > w) return false; for (int z = 0; z < count; ++z) row[4 * (i++) + k] = d[p++]; }
-                }
-            }
-        } else {
-            if (p + (size_t)4 * w > d.size()) return false;
-            memcpy(row, &d[p], (size_t)4 * w); p += (size_t)4 * w;
+        if (p + 4 > d.size()) return false;
+        if (d[p] != 2 || d[p + 1] != 2 || (d[p + 2] & 0x80)) {
+            if (y == 0) { flat = true; break; }
+            return false;
         }
+        if (((d[p + 2] << 8) | d[p + 3]) != w) return false;
+        p += 4;
+        for (int k = 0; k < 4; ++k) {
+            int i = 0;
+            while (i < w) {
+                if (p >= d.size()) return false;
+                int count = d[p++];
+                if (count > 128) { count -= 128; if (p >= d.size() || i + count > w) return false; uint8_t v = d[p++]; for (int z = 0; z < count; ++z) row[4 * (i++) + k] = v; }
+                else { if (count == 0 || p + count > d.size() || i + count > w) return false; for (int z = 0; z < count; ++z) row[4 * (i++) + k] = d[p++]; }
+            }
+        }
+    }
+    if (flat) {
+        if (p + (size_t)4 * w * h > d.size()) return false;
+        memcpy(rgbe.data(), &d[p], (size_t)4 * w * h);
     }
     rgb->assign((size_t)w * h * 3, 0.f);
     for (int y = 0; y < h; ++y) {

@@ -272,6 +272,33 @@ def test_hdr_reader_flat_and_run_length_encoded(tmp_path):
     rle = tmp_path / "rle.hdr"
     rle.write_bytes(bytes(out))
     assert np.array_equal(ra.read_hdr(rle), want)
+    # the committed run-length encoded file (tests/golden/make_env_map.py wrote it with this encoder from these pixels) decodes to the same floats
+    fixture = os.path.join(os.path.dirname(__file__), "golden", "assets", "env_rle_40x9.hdr")
+    assert open(fixture, "rb").read() == bytes(out)
+    assert np.array_equal(ra.read_hdr(fixture), want)
+    # stb_image's rules: a scanline whose length word is not the width is an error; so is a scanline without the 2 2 header after the
+    # first one; a FIRST scanline without it means the whole file is flat
+    hdr_len = raw.index(b"+X %d\n" % w) + len(b"+X %d\n" % w)
+    bad_len = bytearray(out); bad_len[hdr_len + 3] = (w - 1) & 255
+    (tmp_path / "badlen.hdr").write_bytes(bytes(bad_len))
+    with pytest.raises(RuntimeError):
+        ra.read_hdr(tmp_path / "badlen.hdr")
+    row1 = hdr_len
+    for _ in range(1):                                            # find the start of the second scanline by decoding the first
+        q = row1 + 4
+        for c in range(4):
+            i = 0
+            while i < w:
+                cnt = out[q]; q += 1
+                if cnt > 128:
+                    q += 1; i += cnt - 128
+                else:
+                    q += cnt; i += cnt
+        row1 = q
+    mixed = bytes(out[:row1]) + rgbe[1:].tobytes()                # first scanline encoded, the rest flat
+    (tmp_path / "mixed.hdr").write_bytes(mixed)
+    with pytest.raises(RuntimeError):
+        ra.read_hdr(tmp_path / "mixed.hdr")
     (tmp_path / "bad.hdr").write_bytes(raw[:40])
     with pytest.raises(RuntimeError):
         ra.read_hdr(tmp_path / "bad.hdr")
