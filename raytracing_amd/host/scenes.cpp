@@ -5,6 +5,7 @@
 //   "cornell"   Cornellbox()      :46-192
 //   "sphere1"   sphere1()         :344-408
 //   "helmet"    DamagedHelmet()   :218-316
+//   "mrspheres" MetalRoughSphere() :194-216 (the model's geometry buffer is absent from the reference; see BuildMRSpheres)
 //   "spheres2"  sphere1() plus a GlassMaterial sphere and an earth-textured sphere
 //               (the Lambertian / metal / dielectric + earthmap configuration)
 //   "cornell_metal", "spheres3"  test scenes for branches the shipped scenes never take (see BuildCornellMetal, BuildSpheres)
@@ -230,6 +231,21 @@ void BuildHelmet(BuiltScene &bs, const std::string &assets, const std::string &m
     bs.lookat = LookAt(Point3f(1.f + ts, 0.7f + ts, -1.f + ts), Point3f(-0.5f + ts, -0.2f + ts, 0.3f + ts), Vector3f(0.0f, 1.0f, 0.0f));
 }
 
+// MetalRoughSphere() (RayTracing.cpp:194-216): the glTF sample model under RotateZ(180) RotateY(180) RotateX(-90), one
+// MetalRoughnessMaterial per mesh from the model's two textures, no light (so the sky gradient lights the scene), eye (0, 0, 50).
+void BuildMRSpheres(BuiltScene &bs, const std::string &assets) {
+    std::vector<std::shared_ptr<Primitive>> prims; std::vector<std::shared_ptr<Light>> lights;
+    Transform o2w = RotateZ(180) * RotateY(180) * RotateX(-90) * Transform();
+    bs.loaders.emplace_back(new ModelLoad);
+    ModelLoad &ML = *bs.loaders.back();
+    const std::string model = assets + "/MetalRoughSpheres/glTF/MetalRoughSpheres.gltf";
+    ML.loadModel(model, o2w);
+    if (ML.meshes.empty()) throw std::runtime_error("mrspheres: could not load " + model + " (its geometry buffer MetalRoughSpheres0.bin is not part of the reference; tests/mrspheres_bin.py writes a stand-in)");
+    ML.buildTextureModel(o2w, prims);
+    bs.scene = make_shared<Scene>(make_shared<BVHAccel>(prims), lights);
+    bs.lookat = LookAt(Point3f(0.f, 0.f, 50.0f), Point3f(0.f, 0.f, 0.0f), Vector3f(0.0f, 1.0f, 0.0f));
+}
+
 // PCG32 (O'Neill 2014), sequence 0xC0FFEE.
 struct Pcg {
     uint64_t state = 0, inc = 0;
@@ -287,6 +303,7 @@ rth_scene *rth_scene_build(const char *name, const char *assets_dir, int64_t par
         else if (nm == "spheres_env") BuildSpheres(h->b, true, assets, false, true);
         else if (nm == "helmet") BuildHelmet(h->b, assets);
         else if (nm == "helmet_glb") BuildHelmet(h->b, assets, "/DamagedHelmet/glTF-Binary/DamagedHelmet.glb");   // the same model as one binary container
+        else if (nm == "mrspheres") BuildMRSpheres(h->b, assets);
         else if (nm == "soup") BuildSoup(h->b, param);
         else throw std::runtime_error("unknown scene '" + nm + "'");
         if (!h->b.flat) h->b.flat = FlattenScene(*h->b.scene);

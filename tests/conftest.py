@@ -30,6 +30,9 @@ def host_scene():
     def get(name, param=0):
         key = (name, param)
         if key not in _scene_cache:
+            if name == "mrspheres":       # the model's geometry buffer is not in the reference repository: a synthetic one is written on first use
+                import mrspheres_bin
+                mrspheres_bin.ensure(ra.default_assets_dir())
             _scene_cache[key] = ra.HostScene(name, param)
         return _scene_cache[key]
     return get

@@ -17,6 +17,7 @@ CAMERAS = {   # eye, look, up of the reference's scene functions (RayTracing.cpp
     "cornell_env": ((2.5, 2.5, 11.8), (2.5, 2.5, 0.0), (0, 1, 0)),
     "spheres_env": ((13, 2, 3), (0, 0, 0), (0, 1, 0)),
     "helmet": ((3.5, 3.2, 1.5), (2.0, 2.3, 2.8), (0, 1, 0)),
+    "mrspheres": ((0, 0, 50), (0, 0, 0), (0, 1, 0)),      # MetalRoughSphere(), RayTracing.cpp:214
 }
 
 
@@ -85,3 +86,13 @@ def cam_spec(name, w, h):
     return struct.pack("<11f2i", *eye, *look, *up, 40.0, 0.01, w, h)
 
 
+
+
+def same_tree(g, nodes, order):
+    """Is (nodes, order) the tree of the golden file g (ref_bvh_<scene>.npz)?  Large trees are stored as SHA-256 digests of the
+    reference's node and leaf-order bytes instead of the bytes themselves."""
+    import hashlib
+    if "nodes_sha256" in g.files:
+        return (len(nodes) == int(g["n_nodes"]) and hashlib.sha256(nodes.tobytes()).hexdigest() == str(g["nodes_sha256"]) and
+                hashlib.sha256(np.ascontiguousarray(order, np.int32).tobytes()).hexdigest() == str(g["order_sha256"]))
+    return len(nodes) == int(g["n_nodes"]) and nodes.tobytes() == g["nodes"].tobytes() and np.array_equal(order, g["order"])

