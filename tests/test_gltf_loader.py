@@ -110,3 +110,33 @@ def test_base64_buffers_and_matrix_nodes(tmp_path):
     p1, _, _ = ra.model_probe(path, apply_node_transforms=True)
     want = (pos[idx] * np.array([3, 1, 1]) + np.array([10, 2, 0])) * np.array([1, 1, -1])
     assert np.allclose(p1.reshape(6, 3), want)
+
+
+def test_metal_rough_spheres_file_with_every_mesh_and_both_textures():
+    """MetalRoughSpheres.gltf as the reference ships it (five meshes under one parent node with a matrix, one material, 16-bit indices
+    into three shared buffer views) over a synthetic geometry buffer of the stated layout (the reference lacks the .bin): ModelLoad
+    walks the children in file order (5, 4, 3, 2, 1), takes every mesh whole, ignores the node matrix unless told otherwise, and hands
+    back the material's two texture names; with node transforms applied the parent's 0.4 scale and axis swap show in the bounds."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mrspheres_bin
+    mrspheres_bin.ensure(ASSETS)
+    path = os.path.join(ASSETS, "MetalRoughSpheres", "glTF", "MetalRoughSpheres.gltf")
+    g = json.load(open(path))
+    counts = [g["accessors"][m["primitives"][0]["indices"]]["count"] // 3 for m in g["meshes"]]
+    p, uv, names = ra.model_probe(path)
+    assert len(p) == sum(counts) == 501776
+    assert names == ("Spheres_BaseColor.png", "Spheres_MetalRough.png")
+    # node 0 lists its children as 5, 4, 3, 2, 1 = meshes 4, 3, 2, 1, 0: the triangles arrive in that order
+    order = [4, 3, 2, 1, 0]
+    start = 0
+    for mi in order:
+        acc = g["accessors"][g["meshes"][mi]["primitives"][0]["attributes"]["POSITION"]]
+        blk = p[start:start + counts[mi]].reshape(-1, 3)
+        lo, hi = np.array(acc["min"]), np.array(acc["max"])
+        # (the loader negates z: aiProcess_MakeLeftHanded, modelload.cpp:9)
+        assert blk[:, 0].min() >= lo[0] - 1e-4 and blk[:, 0].max() <= hi[0] + 1e-4 and (-blk[:, 2]).min() >= lo[2] - 1e-4 and (-blk[:, 2]).max() <= hi[2] + 1e-4
+        start += counts[mi]
+    assert uv.min() >= -1e-6 and uv.max() <= 1 + 1e-6
+    q, _, _ = ra.model_probe(path, apply_node_transforms=True)
+    assert len(q) == len(p) and np.abs(q).max() < 0.41 * np.abs(p).max() + 1e-3 and np.abs(q).max() > 0.39 * np.abs(p).max()
