@@ -210,6 +210,8 @@ typedef struct rt_trace_stats {
     uint64_t nodes_visited;    /* slab tests performed (reference traversal order) */
     uint64_t prims_tested;     /* primitive tests performed */
     double   seconds;          /* average kernel time over `repeats`, HIP events */
+    uint64_t rays_replayed;    /* rays of the last launch whose order-free walk was not conclusive and that were walked again in the
+                                  order of BVHAccel::Intersect (rt_trace_closest_device only) */
 } rt_trace_stats;
 
 typedef struct rt_ctx   rt_ctx;

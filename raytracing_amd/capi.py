@@ -80,7 +80,7 @@ class RenderStats(C.Structure):
 
 
 class TraceStats(C.Structure):
-    _fields_ = [("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64), ("seconds", C.c_double)]
+    _fields_ = [("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64), ("seconds", C.c_double), ("rays_replayed", C.c_uint64)]
 
 
 RT_RENDER_ACCUMULATE = 1

@@ -218,9 +218,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_batch(DevScene sc, size_t n,
 #ifndef RT_TRACE_OCC
 #define RT_TRACE_OCC 4          // waves per SIMD the batch trace kernels are compiled for (they are launched four blocks to a CU: five lose to L2 thrash)
 #endif
-template <bool ANY, bool COUNT, bool QUAD>
+// FREE (closest hit over quad records only): the order-free walk of rt_traverse2.h; a ray whose answer is not safe against the
+// reference's visit order gets primitive -2 and its index goes on `replay` (replay[0] = count, then the indices), which a second
+// launch of the ordered kernel works through (items / n_items: that launch's indirection).
+template <bool ANY, bool COUNT, bool QUAD, bool FREE = false>
 __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene sc, size_t n, const float *__restrict__ rays, int aos, int *out_prim, float *out_t,
-                                                           float *out_b1, float *out_b2, uint8_t *out_any, int *spill, unsigned long long *work, int leaf_min) {
+                                                           float *out_b1, float *out_b2, uint8_t *out_any, int *spill, unsigned long long *work, int leaf_min,
+                                                           uint32_t *replay = nullptr, const uint32_t *items = nullptr, const uint32_t *n_items = nullptr) {
+    static_assert(!FREE || (!ANY && !COUNT && QUAD), "the order-free walk is a closest-hit walk over quad records");
     constexpr int RING = QUAD ? RT_QUAD_STACK : RT_PAIR_STACK;
     __shared__ int s_si[RING * RT_BLOCK];
     __shared__ float s_st[RING * RT_BLOCK];
@@ -229,8 +234,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene
     st.cap = QUAD ? sc.quad_stack_cap : RT_MAX_STACK;
     st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     size_t nwaves = nthreads / RT_WAVE, gw = gtid / RT_WAVE;
-    size_t per = ((n + nwaves - 1) / nwaves + RT_WAVE - 1) & ~(size_t)(RT_WAVE - 1);
-    size_t w_lo = gw * per < n ? gw * per : n, w_hi = w_lo + per < n ? w_lo + per : n;
+    const size_t m = n_items ? (size_t)*n_items : n;      // work items: all n rays, or the listed ones
+    size_t per = ((m + nwaves - 1) / nwaves + RT_WAVE - 1) & ~(size_t)(RT_WAVE - 1);
+    size_t w_lo = gw * per < m ? gw * per : m, w_hi = w_lo + per < m ? w_lo + per : m;
     size_t next = w_lo;
     long long ri = -1;
     LaneTrav L = {};
@@ -257,6 +263,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene
                         b2 = acosf(clampf(ph.z / sp[0], -1.f, 1.f)) / RT_PI;
                     }
                 }
+                if (FREE && L.amb) { prim = -2; replay[1 + atomicAdd(&replay[0], 1u)] = (uint32_t)i; }
                 out_prim[i] = prim; out_t[i] = L.tmax;
                 if (out_b1) { out_b1[i] = b1; out_b2[i] = b2; }
             }
@@ -269,8 +276,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene
         if (im != 0 && next < w_hi) {
             size_t cand = next + prefix_in_mask(im);
             if (ri < 0 && cand < w_hi) {
-                ri = (long long)cand;
-                size_t i = cand;
+                size_t i = items ? (size_t)items[cand] : cand;
+                ri = (long long)i;
                 if (aos) { po = f3(rays[7 * i], rays[7 * i + 1], rays[7 * i + 2]); pd = f3(rays[7 * i + 3], rays[7 * i + 4], rays[7 * i + 5]); ptmax = rays[7 * i + 6]; }
                 else { po = f3(rays[i], rays[n + i], rays[2 * n + i]); pd = f3(rays[3 * n + i], rays[4 * n + i], rays[5 * n + i]); ptmax = rays[6 * n + i]; }
                 fresh = true;
@@ -288,11 +295,23 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene
         float4 pre[3];
         if (leafrun) { const float4 *sl = sc.slots + 3 * (size_t)L.cur; pre[0] = sl[0]; pre[1] = sl[1]; pre[2] = sl[2]; }
 #endif
-        if (QUAD) {
+        float entry = 0.f;
+        if (FREE) { if (walk) lane_walk_quad_free(sc.quads, L, st, info, have, entry); }
+        else if (QUAD) {
             if (__ballot(walk && !L.plain) == 0 && !exact_slabs) { if (walk) lane_walk_quad<true>(sc.quads, L, st, info, have); }     // the whole wave takes one version
             else if (walk) lane_walk_quad<false>(sc.quads, L, st, info, have);
         } else if (walk) lane_walk<COUNT, false>(sc.pairs, L, st, nNodes, info, have);
-        if (leafrun) {
+        if (FREE) {
+            if (leafrun) {
+#if RT_LEAF_LOAD_AHEAD
+                LeafOutFree r = lane_leaf_free(sc, sc.slots, L, st, pre);
+#else
+                LeafOutFree r = lane_leaf_free(sc, sc.slots, L, st);
+#endif
+                L.found = r.found; L.amb = r.amb; L.tmax = r.tmax; L.hitSlot = r.hitSlot; L.b0 = r.b0; L.b1 = r.b1; L.b2 = r.b2;
+                info = r.info; have = r.have; entry = r.entry;
+            }
+        } else if (leafrun) {
 #if RT_LEAF_LOAD_AHEAD
             LeafOut r = lane_leaf<ANY, COUNT>(sc, sc.slots, L, st, nTests, pre);
 #else
@@ -301,8 +320,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene
             L.found = r.found; L.tmax = r.tmax; L.hitSlot = r.hitSlot; L.b0 = r.b0; L.b1 = r.b1; L.b2 = r.b2;
             info = r.info; have = r.have;
         }
-        if (fresh) { have = lane_begin<COUNT>(sc, L, st, po, pd, ptmax, nNodes); info = sc.root_info; }
-        if (walk || leafrun || fresh) lane_enter(sc, L, info, have);
+        if (fresh) {
+            if (FREE) have = lane_begin_free(sc, L, st, po, pd, ptmax); else have = lane_begin<COUNT>(sc, L, st, po, pd, ptmax, nNodes);
+            info = sc.root_info;
+        }
+        if (walk || leafrun || fresh) { lane_enter(sc, L, info, have); if (FREE) L.entry = entry; }
     }
     if (COUNT) {
         atomicAdd(&work[0], (unsigned long long)nNodes);
@@ -1745,12 +1767,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow_carry(DevScene sc, int boun
 // wave-wide append (emission, class binning, adding the unoccluded light) runs afterwards as a second, coalesced sweep
 // over the block's share.
 enum { RT_WALK_QUADS = 1, RT_WALK_PAIRS = 2 };
+#ifndef RT_FREE_SPECULATE
+#define RT_FREE_SPECULATE 0         // order-free persistent walk: lanes that hold an untested leaf walk ahead (trace_share); measured slower, see there
+#endif
+#ifndef RT_FREE_LEAF_MIN
+#define RT_FREE_LEAF_MIN 32         // ... and the leaves are tested once this many lanes of the wave hold one
+#endif
 
 struct RayArrays { const float *ox, *oy, *oz, *dx, *dy, *dz; };
 
 // Traverse this wave's chunks of the `total` concatenated positions of a segmented queue; sink(i, L) receives each finished ray
 // (i = its position in the queue arrays).  recs = pair or quad records (LDS or global), slots = leaf slots.
-template <bool ANY, int MODE, class Stack, class Sink>
+// FREE (closest hit over quad records): the order-free walk of rt_traverse2.h; the sink sees L.amb on rays that have to be walked again
+// in the reference's order.
+template <bool ANY, int MODE, bool FREE = false, class Stack, class Sink>
 __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *recs, const float4 *slots, RayArrays ra, float tmax0, uint32_t total,
                                             const uint32_t *s_prefix, uint32_t segcap, Stack &st, float *s_ray, Sink sink) {
     const uint32_t lane = lane_id();
@@ -1780,6 +1810,12 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
     uint32_t cur_i = 0, dummy = 0;
     // Every lane is walking, waiting at a leaf, or idle (finished / never started).  Each round the wave runs ONE of the
     // three phases, the one most lanes are waiting for, so the instructions of a phase are issued for a well-filled wave.
+    // FREE: a lane that holds a leaf still to be tested need not wait for the leaf phase: the order of the visits is free, so in a walk
+    // phase it takes the next record within reach from its stack and expands it, all grandchildren going back on the stack (the leaf's
+    // primitives may yet shorten the reach: what was pushed is looked at again when it is popped).  The lanes that wait for the majority's
+    // phase thus do work that is needed unless the pending leaf turns out to hold the hit.  A lane whose stack top is another leaf, or
+    // empty, cannot walk ahead (spec_blocked) until its leaf has been tested.
+    bool spec_blocked = false;
     while (true) {
         const bool walk = busy && L.mode == RT_LANE_WALK, leaf = busy && L.mode == RT_LANE_LEAF, idle = !busy || L.mode == RT_LANE_DONE;
         const uint64_t im = __ballot(idle);
@@ -1787,8 +1823,26 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
         const uint32_t supply = avail + pf_count, nIdle = (uint32_t)__popcll(im), nI = nIdle < supply ? nIdle : supply;
         if (nW == 0 && nL == 0 && nI == 0) break;
         uint32_t info = 0; bool have = false, moved = false;
-        if (nW >= nL && nW >= nI) {
-            if (MODE == RT_WALK_QUADS) {
+        float entry = 0.f;
+        const bool can_spec = FREE && RT_FREE_SPECULATE && leaf && !spec_blocked;
+        const uint32_t nS = FREE && RT_FREE_SPECULATE ? (uint32_t)__popcll(__ballot(can_spec)) : 0u;
+        // which phase: without walking ahead, the one most lanes wait for; with it, leaves are tested once RT_FREE_LEAF_MIN lanes hold one or
+        // nobody has a record of its own to walk, otherwise walkers and lanes walking ahead against the idle lanes
+        const bool leaf_phase = FREE && RT_FREE_SPECULATE ? (nL >= RT_FREE_LEAF_MIN || (nW == 0 && nL > 0 && nL >= nI)) : (!(nW >= nL && nW >= nI) && nL >= nI);
+        const bool walk_phase = !leaf_phase && (FREE && RT_FREE_SPECULATE ? (nW + nS > 0 && nW + nS >= nI) : (nW >= nL && nW >= nI));
+        if (walk_phase) {
+            if (FREE) {
+                uint32_t node = (uint32_t)L.cur; bool step = walk;
+                if (can_spec) {
+                    uint32_t e; float et;
+                    if (stack_next_free(free_reach(L), st, e, et)) {
+                        if (e & RT_PAIR_LEAF) { st.push((int)e, et); spec_blocked = true; }
+                        else { node = e; step = true; }
+                    } else spec_blocked = true;
+                }
+                if (step) quad_step_free(recs, L, node, !walk, st, info, have, entry);
+            }
+            else if (MODE == RT_WALK_QUADS) {
                 if (__ballot(walk && !L.plain) == 0) { if (walk) lane_walk_quad<true, ANY>(recs, L, st, info, have); }     // the whole wave takes one version
                 else if (walk) lane_walk_quad<false, ANY>(recs, L, st, info, have);
             } else {
@@ -1796,8 +1850,15 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
                 else if (walk) lane_walk<false, false, 1, ANY>(recs, L, st, dummy, info, have);
             }
             moved = walk;
-        } else if (nL >= nI) {
-            if (leaf) {
+        } else if (leaf_phase) {
+            if (FREE) {
+                if (leaf) {
+                    LeafOutFree r = lane_leaf_free(sc, slots, L, st);
+                    L.found = r.found; L.amb = r.amb; L.tmax = r.tmax; L.hitSlot = r.hitSlot; L.b0 = r.b0; L.b1 = r.b1; L.b2 = r.b2;
+                    info = r.info; have = r.have; entry = r.entry;
+                    spec_blocked = false;
+                }
+            } else if (leaf) {
                 LeafOut r = lane_leaf<ANY, false, ANY>(sc, slots, L, st, dummy);
                 L.found = r.found; L.tmax = r.tmax; L.hitSlot = r.hitSlot; L.b0 = r.b0; L.b1 = r.b1; L.b2 = r.b2;
                 info = r.info; have = r.have;
@@ -1820,16 +1881,17 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
                 F3 po = f3(s_ray[k], s_ray[RT_WAVE + k], s_ray[2 * RT_WAVE + k]), pd = f3(s_ray[3 * RT_WAVE + k], s_ray[4 * RT_WAVE + k], s_ray[5 * RT_WAVE + k]);
                 cur_i = __float_as_uint(s_ray[6 * RT_WAVE + k]);
                 busy = true; moved = true;
-                have = lane_begin<false>(sc, L, st, po, pd, tmax0, dummy); info = sc.root_info;
+                if (FREE) have = lane_begin_free(sc, L, st, po, pd, tmax0); else have = lane_begin<false>(sc, L, st, po, pd, tmax0, dummy);
+                info = sc.root_info;
             }
             rd += take; avail -= take;
         }
-        if (moved) lane_enter(sc, L, info, have);
+        if (moved) { lane_enter(sc, L, info, have); if (FREE) L.entry = entry; }
     }
     if (busy && L.mode == RT_LANE_DONE) sink(cur_i, L);
 }
 
-template <int MODE>
+template <int MODE, bool FREE = false>
 __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend_pl(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
                                                          uint32_t segcap, float4 *lbuf, BounceCounts *counts, BounceStats *stats, int *spill) {
     __shared__ int s_si[RT_FRAME_RING * RT_BLOCK];
@@ -1848,12 +1910,14 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend_pl(DevScene sc, RenderPa
     st.cap = MODE == RT_WALK_QUADS ? sc.quad_stack_cap : RT_MAX_STACK;
     st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     RayArrays ra = {q.ox, q.oy, q.oz, q.dx, q.dy, q.dz};
-    trace_share<false, MODE>(sc, recs, slots, ra, RT_INF, total, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE],
+    trace_share<false, MODE, FREE>(sc, recs, slots, ra, RT_INF, total, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE],
                              [&](uint32_t i, const LaneTrav &L) {
-                                 hb.slot[i] = L.found ? L.hitSlot : -1; hb.t[i] = L.tmax; hb.b0[i] = L.b0; hb.b1[i] = L.b1; hb.b2[i] = L.b2;
+                                 // (order-free walk: -2 marks a ray the second sweep walks again in the reference's order)
+                                 hb.slot[i] = (FREE && L.amb) ? -2 : (L.found ? L.hitSlot : -1); hb.t[i] = L.tmax; hb.b0[i] = L.b0; hb.b1[i] = L.b1; hb.b2[i] = L.b2;
                              });
     __threadfence_block();
     __syncthreads();
+    uint32_t n_replayed = 0;
     // second sweep, coalesced, every wave over its own chunks: emission / sky / termination (integrator.cpp:242-257) and class binning
     uint32_t seg = 0;
     const uint32_t seg_base = blockIdx.x * segcap;
@@ -1867,6 +1931,13 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend_pl(DevScene sc, RenderPa
             while (g >= s_prefix[seg + 1]) seg++;
             i = seg * segcap + (g - s_prefix[seg]);
             int slot = hb.slot[i];
+            if (FREE && slot == -2) {      // near-tie (or a ray that is not plain): BVHAccel::Intersect's own order decides
+                LaneTrav R = {};
+                trace_one<false, 1, true>(sc, sc.quads, sc.slots, f3(q.ox[i], q.oy[i], q.oz[i]), f3(q.dx[i], q.dy[i], q.dz[i]), RT_INF, st, R);
+                slot = R.found ? R.hitSlot : -1;
+                hb.slot[i] = slot; hb.t[i] = R.tmax; hb.b0[i] = R.b0; hb.b1[i] = R.b1; hb.b2[i] = R.b2;
+                n_replayed++;
+            }
             bool found = slot >= 0;
             uint32_t state = q.state[i];
             int depth = state & 0xFFFF; bool spec = (state >> 16) & 1;
@@ -1907,6 +1978,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend_pl(DevScene sc, RenderPa
     }
     __syncthreads();
     if (threadIdx.x < RT_NUM_CLASSES) bc->cls[threadIdx.x][blockIdx.x] = s_cls[threadIdx.x];
+    if (FREE && n_replayed) atomicAdd(&stats[bounce].n_replay, n_replayed);      // statistics only
 }
 
 template <int MODE>
@@ -2045,7 +2117,7 @@ struct rt_scene {
     DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_envs, d_light_cdf, d_spill, d_pairs, d_quads, d_flat;
     int interior_depth = 0;
     std::vector<DevBuf *> d_texels;
-    DevBuf d_trace_io, d_work;
+    DevBuf d_trace_io, d_work, d_replay;      // d_replay: count + indices of the rays the order-free batch trace hands to the ordered one
     size_t spill_bytes = 0;
     // Rendering runs as up to RT_MAX_LANES independent wavefront pipelines ("lanes") at once, each on its own HIP stream with its own
     // queues, over its own share of the samples (rt_render_device).  Lane 0 runs on the context's stream and owns the result buffer.
@@ -2501,18 +2573,31 @@ int rt_scene_get_bvh(rt_scene *this_, rt_bvh_node *nodes_out, int32_t *n_nodes_o
     return 0;
 }
 
+// Closest hits of the batch trace through the order-free walk (with the ordered replay of what it flags)?  Needs quad records.  Off unless
+// RT_AMD_FREE_WALK=1: on the 10 M-triangle soup the nearest-first order visits no fewer records than the reference's order by split
+// axis and ray sign does, and the kernel is bound by those fetches (28.4 ms ordered, 29.8 ms order-free, 105 of 16.7 M rays replayed);
+// kept as a cross-check of the order-free primitives that the frame kernels use.
+static bool free_walk_enabled(rt_scene *s) { return s->dev.quads != nullptr && env_int("RT_AMD_FREE_WALK", 0) != 0 && !env_int("RT_AMD_NODE_WALK", 0); }
+
 // Batch trace launch: quad records when the scene has them, pair records otherwise and for the counting variant (whose
 // counts are the reference's per-node and per-primitive test counts).
 extern "C++" {
 template <bool ANY, bool COUNT>
 static void launch_trace(rt_scene *this_, int grid, size_t n, const float *rays, int aos, int *prim, float *t, float *b1, float *b2, uint8_t *any_out,
-                         unsigned long long *work, int *spill = nullptr, bool allow_node_walk = true) {
+                         unsigned long long *work, int *spill = nullptr, bool allow_node_walk = true, uint32_t *replay = nullptr) {
     rt_ctx *ctx = this_->ctx;
     if (!spill) spill = (int *)this_->d_spill.p;      // the scene's own spill area, sized for the largest grid (rt_scene_create)
     if (allow_node_walk && env_int("RT_AMD_NODE_WALK", 0))      // knob: the one-node-per-step walk the frame kernels use
         hipLaunchKernelGGL((k_trace_batch<ANY, COUNT>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
                            spill, work);
-    else if (!COUNT && this_->dev.quads)
+    else if (!ANY && !COUNT && this_->dev.quads && replay) {
+        // closest hits without the reference's visit order, then the rays whose answer that order could change, in that order
+        (void)hipMemsetAsync(replay, 0, 4, ctx->stream);
+        hipLaunchKernelGGL((k_trace_pairs<false, false, true, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
+                           spill, work, tune_leaf_min(), replay, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+        hipLaunchKernelGGL((k_trace_pairs<false, false, true>), dim3(std::min(grid, 64)), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
+                           spill, work, tune_leaf_min(), (uint32_t *)nullptr, (const uint32_t *)(replay + 1), (const uint32_t *)replay);
+    } else if (!COUNT && this_->dev.quads)
         hipLaunchKernelGGL((k_trace_pairs<ANY, false, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
                            spill, work, tune_leaf_min());
     else
@@ -2534,11 +2619,13 @@ static int trace_host(rt_scene *this_, bool any, size_t n, const float *o, const
     HIP_OK(hipMemcpyAsync(base, rays.data(), in_bytes, hipMemcpyHostToDevice, ctx->stream));
     char *outp = base + ((in_bytes + 255) & ~(size_t)255);
     int grid = (int)std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)ctx->n_cu * trace_blocks_per_cu());
+    uint32_t *replay = nullptr;
+    if (!any && free_walk_enabled(this_)) { HIP_OK(this_->d_replay.ensure(4 * (n + 1))); replay = (uint32_t *)this_->d_replay.p; }
     if (any)
         launch_trace<true, false>(this_, grid, n, (const float *)base, 1, nullptr, nullptr, nullptr, nullptr, (uint8_t *)outp, nullptr);
     else
         launch_trace<false, false>(this_, grid, n, (const float *)base, 1, (int *)outp, (float *)outp + n, (float *)outp + 2 * n, (float *)outp + 3 * n, nullptr,
-                                   nullptr);
+                                   nullptr, nullptr, true, replay);
     HIP_OK(hipGetLastError());
     if (any) HIP_OK(hipMemcpyAsync(out_hit, outp, n, hipMemcpyDeviceToHost, ctx->stream));
     else {
@@ -2579,17 +2666,20 @@ int rt_trace_closest_device(rt_scene *this_, size_t n, const void *rays, void *h
         HIP_OK(hipStreamSynchronize(ctx->stream));
         if (stats) { stats->nodes_visited = w[0]; stats->prims_tested = w[1]; }
     }
+    uint32_t *replay = nullptr;
+    if (free_walk_enabled(this_)) { HIP_OK(this_->d_replay.ensure(4 * (n + 1))); replay = (uint32_t *)this_->d_replay.p; }
     EventPair ev;
     HIP_OK(ev.create());
     HIP_OK(hipEventRecord(ev.a, ctx->stream));
     for (int r = 0; r < repeats; ++r)
-        launch_trace<false, false>(this_, grid, n, (const float *)rays, 0, prim, t, b1, b2, nullptr, nullptr);
+        launch_trace<false, false>(this_, grid, n, (const float *)rays, 0, prim, t, b1, b2, nullptr, nullptr, nullptr, true, replay);
     HIP_OK(hipEventRecord(ev.b, ctx->stream));
     HIP_OK(hipEventSynchronize(ev.b));
     HIP_OK(hipGetLastError());
     float ms = 0.f;
     HIP_OK(hipEventElapsedTime(&ms, ev.a, ev.b));
     if (stats) stats->seconds = (double)ms * 1e-3 / repeats;
+    if (stats && replay) { uint32_t nr = 0; HIP_OK(hipMemcpy(&nr, replay, 4, hipMemcpyDeviceToHost)); stats->rays_replayed = nr; }
     return 0;
 }
 
@@ -2816,6 +2906,12 @@ static int render_lane(rt_scene *this_, RenderLane &ln, const rt_camera *cam, co
     // incoherent bounces of LDS scenes with few leaves: no walk, every leaf box tested in lockstep (k_extend_flat)
     const bool use_flat = lds_scene && round_pairs && !frame_old && this_->dev.flat != nullptr && env_int("RT_AMD_FLAT", 1) != 0;
     const int flat_from = env_int("RT_AMD_FLAT_FROM", 1);
+    // later bounces on large trees: the persistent-lane walk without the reference's visit order (near-ties walked again in that order).
+    // Off unless RT_AMD_FREE_PL=1.  Measured on the helmet, 1440 x 1440 @ 64 spp: nearest-first order alone 575 Msamples/s against 574 in the
+    // reference's order (7 rays in 100 000 replayed) — the split-axis order is as good a guess at "near" as the entry distances; with lanes
+    // that hold an untested leaf walking ahead (RT_FREE_SPECULATE, leaves tested once 8 / 16 / 32 / 48 lanes hold one): 496 / 524 / 540 / 512.
+    // The records fetched ahead are wasted whenever the pending leaf holds the hit, and they cost L1 room and LDS stack traffic.
+    const bool free_pl = env_int("RT_AMD_FREE_PL", 0) != 0;
     // shadow rays traced inside the shading kernels: scenes whose tree and tables both sit in LDS
     // (only while five blocks of the fused kernel still share a CU's 160 KB of LDS: 25.6 KB static + the scene's tables <= 32 KB)
     const bool all_in_lds = lds_scene && round_pairs && !frame_old && shade_tables_in_lds(this_->dev) && shade_lds_bytes(this_->dev) <= 6400 && !this_->dev.envs;
@@ -2864,7 +2960,10 @@ static int render_lane(rt_scene *this_, RenderLane &ln, const rt_camera *cam, co
                 else
                     hipLaunchKernelGGL(k_extend<false>, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)ln.d_cls.p,
                                        ucap, useg, lbuf, counts, bstats, ln.spill, round_quads | rr_extend);
-            } else if (walk_mode == RT_WALK_QUADS)
+            } else if (walk_mode == RT_WALK_QUADS && free_pl)
+                hipLaunchKernelGGL((k_extend_pl<RT_WALK_QUADS, true>), dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, rp, b, q[cq], hb,
+                                   (uint32_t *)ln.d_cls.p, ucap, useg, lbuf, counts, bstats, ln.spill);
+            else if (walk_mode == RT_WALK_QUADS)
                 hipLaunchKernelGGL(k_extend_pl<RT_WALK_QUADS>, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, rp, b, q[cq], hb,
                                    (uint32_t *)ln.d_cls.p, ucap, useg, lbuf, counts, bstats, ln.spill);
             else
@@ -3041,7 +3140,10 @@ int rt_render_device(rt_scene *this_, const rt_camera *cam, const rt_render_opts
 struct rt_multi {
     std::vector<rt_ctx *> ctx;
     std::vector<rt_scene *> scene;
-    DevBuf staging;            // on device[0]: one frame of another device's sums at a time
+    // on device[0], one set per other device: a frame-sized staging buffer, the stream its peer copy runs on, the event that says it has landed
+    std::vector<std::unique_ptr<DevBuf>> staging;
+    std::vector<hipStream_t> copy_stream;
+    std::vector<hipEvent_t> copied;
     std::string error;
 };
 static std::string g_multi_error;
@@ -3066,7 +3168,12 @@ const char *rt_multi_last_error(rt_multi *m) { return m ? m->error.c_str() : g_m
 void rt_multi_destroy(rt_multi *m) {
     if (!m) return;
     for (size_t i = 0; i < m->scene.size(); ++i) rt_scene_destroy(m->scene[i]);
-    if (!m->ctx.empty()) { (void)hipSetDevice(m->ctx[0]->device); (void)m->staging.alloc(0); }
+    if (!m->ctx.empty()) {
+        (void)hipSetDevice(m->ctx[0]->device);
+        m->staging.clear();
+        for (hipStream_t st : m->copy_stream) if (st) (void)hipStreamDestroy(st);
+        for (hipEvent_t ev : m->copied) if (ev) (void)hipEventDestroy(ev);
+    }
     for (size_t i = 0; i < m->ctx.size(); ++i) rt_shutdown(m->ctx[i]);
     delete m;
 }
@@ -3121,11 +3228,22 @@ int rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_opts *opt
     auto fail = [&](const char *what, hipError_t e) { m->error = std::string("rt_multi_render: ") + what + ": " + hipGetErrorString(e); return -2; };
     hipError_t e;
     if ((e = hipSetDevice(root->device)) != hipSuccess) return fail("hipSetDevice", e);
-    if (n > 1 && (e = m->staging.ensure(bytes)) != hipSuccess) return fail("staging buffer", e);
+    // every other device's frame travels on a stream of its own into a staging buffer of its own (the copies run side by side, one xGMI
+    // link each); the adds then follow on the root's stream in device order, each waiting only for its own copy
+    while ((int)m->staging.size() < n - 1) {
+        m->staging.emplace_back(new DevBuf); m->copy_stream.push_back(nullptr); m->copied.push_back(nullptr);
+        if ((e = hipStreamCreateWithFlags(&m->copy_stream.back(), hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+        if ((e = hipEventCreateWithFlags(&m->copied.back(), hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+    }
     for (int i = 1; i < n; ++i) {
-        if ((e = hipMemcpyPeerAsync(m->staging.p, root->device, dsum[i], m->ctx[i]->device, bytes, root->stream)) != hipSuccess) return fail("hipMemcpyPeerAsync", e);
+        if ((e = m->staging[i - 1]->ensure(bytes)) != hipSuccess) return fail("staging buffer", e);
+        if ((e = hipMemcpyPeerAsync(m->staging[i - 1]->p, root->device, dsum[i], m->ctx[i]->device, bytes, m->copy_stream[i - 1])) != hipSuccess) return fail("hipMemcpyPeerAsync", e);
+        if ((e = hipEventRecord(m->copied[i - 1], m->copy_stream[i - 1])) != hipSuccess) return fail("hipEventRecord", e);
+    }
+    for (int i = 1; i < n; ++i) {
+        if ((e = hipStreamWaitEvent(root->stream, m->copied[i - 1], 0)) != hipSuccess) return fail("hipStreamWaitEvent", e);
         hipLaunchKernelGGL(k_add_frames, dim3(std::min<size_t>((nfl + RT_BLOCK - 1) / RT_BLOCK, (size_t)root->n_cu * 8)), dim3(RT_BLOCK), 0, root->stream,
-                           (float *)dsum[0], (const float *)m->staging.p, nfl);
+                           (float *)dsum[0], (const float *)m->staging[i - 1]->p, nfl);
     }
     if ((e = hipGetLastError()) != hipSuccess) return fail("k_add_frames", e);
     if ((e = hipMemcpyAsync(out_sum_rgb, dsum[0], bytes, hipMemcpyDeviceToHost, root->stream)) != hipSuccess) return fail("hipMemcpyAsync", e);

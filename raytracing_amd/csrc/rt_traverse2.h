@@ -120,6 +120,10 @@ struct LaneTrav {
     int hitSlot; float b0, b1, b2;
     bool found;
     RayShear shear;      // per-ray constants of the triangle test
+    // order-free closest-hit walks (lane_walk_quad_free / lane_leaf_free) only:
+    float t0;            // the ray's tMax as it came in (tmax holds the best t found so far once found is set)
+    float entry;         // box entry distance of the leaf that is entered / being tested (at least the smallest positive number)
+    bool amb;            // the answer so far is not safe against the reference's visit order: replay the ray in that order
 };
 
 enum { RT_LANE_WALK = 0, RT_LANE_LEAF = 1, RT_LANE_DONE = 2 };
@@ -160,6 +164,7 @@ __device__ __forceinline__ void lane_setup(LaneTrav &L, F3 o, F3 d, float tmax) 
               fabsf(o.z) < RT_INF;
     L.hitSlot = -1; L.b0 = L.b1 = L.b2 = 0.f; L.found = false;
     L.shear = ray_shear(d, L.invDir);
+    L.t0 = tmax; L.entry = 0.f; L.amb = false;
 }
 // Start a ray: slab-test the root (the reference's first loop iteration) and enter it.
 // Returns whether the root is to be entered (info word sc.root_info).
@@ -341,6 +346,126 @@ __device__ __forceinline__ LeafOut lane_leaf(const DevScene &sc, const float4 *s
             if (t < r.tmax) { r.info = (uint32_t)i; r.have = true; }
         }
     }
+    return r;
+}
+
+// ---- closest hit without the reference's visit order (quad records) ----
+// BVHAccel::Intersect (bvh.cpp:247-282) returns the primitive with the smallest t; the order of its visits matters only when two
+// candidates are nearly tied — at equal t the later-tested primitive wins (triangle.cpp:104-111 rejects only '>'), an accepted hit may
+// raise tMax by an ulp (tScaled <= tMax * det is tested, the rounded tScaled / det is stored), and a box entry distance next to a hit
+// distance can fall on either side of '<' (geometry.h:913).  Every one of these needs a second candidate — another primitive's t, or the
+// entry distance of the accepted primitive's own leaf box — within a few ulps of the smallest t.  A primitive's t and barycentrics do
+// not depend on the ray's tMax, only its acceptance does.  So this walk visits nearest boxes first, whatever the split axes say, with bands:
+//   * a box is entered unless its entry distance is at or beyond the reach, min(best t so far * (1 + RT_FREE_CULL_BAND), the ray's own
+//     tMax) — the ray's own tMax is never widened: what the reference would not accept against it is no candidate;
+//   * primitives are tested against that reach; the best t is kept, and a flag says whether any other candidate lies within
+//     RT_FREE_TIE_BAND (relative) of it: a new best clears the flag unless the old best is within the band of it (every earlier
+//     candidate is at or beyond the old best), a candidate that is not better sets it when it is within the band of the best;
+//   * the flag is also set when the accepted primitive's own leaf box is entered beyond its t (the reference might have culled that
+//     leaf against another candidate's t), and from the start for rays that are not plain (zero direction components: NaN slabs);
+//   * a flagged ray is walked again in the reference's order by the caller.
+// Exactness rests on nested boxes (a leaf's box passes the tMax-independent part of Bounds3::IntersectP exactly when its ancestors'
+// do, for a plain ray — the quad records are only built for such trees), on monotonic acceptance (accepted against some tMax,
+// accepted against any larger), and on one assumption: no primitive's computed t lies below the entry distance of a box that holds it
+// by more than the difference of the bands (0.1 %), so that a subtree skipped here cannot hold a hit the reference, arriving there
+// with a larger tMax, would have accepted below the best t found here.
+#ifndef RT_FREE_CULL_BAND
+#define RT_FREE_CULL_BAND 1e-3f
+#endif
+#ifndef RT_FREE_TIE_BAND
+#define RT_FREE_TIE_BAND 1e-5f
+#endif
+__device__ __forceinline__ float free_reach(const LaneTrav &L) { return L.found ? fminf(L.tmax * (1.f + RT_FREE_CULL_BAND), L.t0) : L.t0; }
+// Pop until an entry whose entry distance is within reach turns up.
+template <class Stack>
+__device__ __forceinline__ bool stack_next_free(float reach, Stack &st, uint32_t &info, float &entry) {
+    bool have = false;
+    info = 0; entry = 0.f;
+    while (!have && st.sp > 0) {
+        int i; float t;
+        st.pop(i, t);
+        if (t < reach) { info = (uint32_t)i; entry = t; have = true; }
+    }
+    return have;
+}
+// Start a ray of the order-free walk: as lane_begin, except that a ray that is not plain is flagged and not walked at all.
+template <class Stack>
+__device__ __forceinline__ bool lane_begin_free(const DevScene &sc, LaneTrav &L, Stack &st, F3 o, F3 d, float tmax) {
+    uint32_t dummy = 0;
+    bool have = lane_begin<false>(sc, L, st, o, d, tmax, dummy);
+    if (!L.plain) { L.amb = true; have = false; }
+    return have;
+}
+// One interior step over quad node L.cur for a plain ray: the four grandchildren within reach, nearest first.
+// node: the record to expand (L.cur for a walking lane).  push_all: the nearest grandchild goes on the stack with the others instead of
+// being entered (a lane that holds a leaf still to be tested walks ahead this way, see trace_share).
+template <class Stack>
+__device__ __forceinline__ void quad_step_free(const float4 *quads, const LaneTrav &L, uint32_t node, bool push_all, Stack &st, uint32_t &info, bool &have, float &entry) {
+    const float4 *Q = quads + 8 * (size_t)node;
+    float4 q0 = Q[0], q1 = Q[1], q2 = Q[2], q3 = Q[3], q4 = Q[4], q5 = Q[5], q6 = Q[6];
+    const uint32_t meta = ((const uint32_t *)Q)[28];
+    const float reach = free_reach(L);
+    float t0, t1, t2, t3;
+    bool ok0 = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, L.o, L.invDir, t0);
+    bool ok1 = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, L.o, L.invDir, t1) && (meta & 64u) == 0;      // a leaf child fills both boxes of its side
+    bool ok2 = slab_fast(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, L.o, L.invDir, t2);
+    bool ok3 = slab_fast(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, L.o, L.invDir, t3) && (meta & 128u) == 0;
+    // sort the four (entry distance, info word) pairs by distance with a five-comparator network on the distances' bit patterns (never
+    // negative: max with the smallest positive number; a candidate out of reach sorts last as all ones).  Compare-and-select on both
+    // halves of a pair: selecting the info words through the position instead makes the compiler build a lookup table in scratch memory.
+    const float tiny = __uint_as_float(1u);
+    uint32_t ka = (ok0 && t0 < reach) ? __float_as_uint(fmaxf(t0, tiny)) : ~0u, ia = __float_as_uint(q6.x);
+    uint32_t kb = (ok1 && t1 < reach) ? __float_as_uint(fmaxf(t1, tiny)) : ~0u, ib = __float_as_uint(q6.y);
+    uint32_t kc = (ok2 && t2 < reach) ? __float_as_uint(fmaxf(t2, tiny)) : ~0u, ic = __float_as_uint(q6.z);
+    uint32_t kd = (ok3 && t3 < reach) ? __float_as_uint(fmaxf(t3, tiny)) : ~0u, id = __float_as_uint(q6.w);
+    auto order = [](uint32_t &k0_, uint32_t &i0_, uint32_t &k1_, uint32_t &i1_) {
+        const bool sw = k1_ < k0_;
+        const uint32_t lk = sw ? k1_ : k0_, hk = sw ? k0_ : k1_, li = sw ? i1_ : i0_, hi = sw ? i0_ : i1_;
+        k0_ = lk; k1_ = hk; i0_ = li; i1_ = hi;
+    };
+    order(ka, ia, kb, ib); order(kc, ic, kd, id); order(ka, ia, kc, ic); order(kb, ib, kd, id); order(kb, ib, kc, ic);
+    if (kd != ~0u) st.push((int)id, __uint_as_float(kd));
+    if (kc != ~0u) st.push((int)ic, __uint_as_float(kc));
+    if (kb != ~0u) st.push((int)ib, __uint_as_float(kb));
+    if (push_all) {
+        if (ka != ~0u) st.push((int)ia, __uint_as_float(ka));
+        have = false; info = 0; entry = 0.f;
+        return;
+    }
+    have = ka != ~0u;
+    info = ia; entry = __uint_as_float(ka);
+    if (!have) have = stack_next_free(reach, st, info, entry);
+}
+template <class Stack>
+__device__ __forceinline__ void lane_walk_quad_free(const float4 *quads, const LaneTrav &L, Stack &st, uint32_t &info, bool &have, float &entry) {
+    quad_step_free(quads, L, (uint32_t)L.cur, false, st, info, have, entry);
+}
+// Test the primitives of the pending leaf (entered at distance <= L.entry) and pick the next node.
+struct LeafOutFree { bool found, amb; float tmax; int hitSlot; float b0, b1, b2; uint32_t info; bool have; float entry; };
+template <class Stack>
+__device__ __forceinline__ LeafOutFree lane_leaf_free(const DevScene &sc, const float4 *slots, const LaneTrav &L, Stack &st, const float4 *first = nullptr) {
+    LeafOutFree r; r.found = L.found; r.amb = L.amb; r.tmax = L.tmax; r.hitSlot = L.hitSlot; r.b0 = L.b0; r.b1 = L.b1; r.b2 = L.b2;
+    for (int i = 0; i < L.count; ++i) {
+        int slot = L.cur + i;
+        float4 r0, r1, r2;
+        if (first && i == 0) { r0 = first[0]; r1 = first[1]; r2 = first[2]; }
+        else { r0 = slots[3 * (size_t)slot]; r1 = slots[3 * (size_t)slot + 1]; r2 = slots[3 * (size_t)slot + 2]; }
+        const uint32_t flags = __float_as_uint(r2.y);
+        const float reach = r.found ? fminf(r.tmax * (1.f + RT_FREE_CULL_BAND), L.t0) : L.t0;
+        float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+        bool ok;
+        if (flags & RT_SLOT_SPHERE) ok = sphere_test(sc.spheres + 32 * (size_t)__float_as_int(r2.w), L.o, L.d, reach, t);
+        else ok = triangle_test_sheared(f3(r0.x, r0.y, r0.z), f3(r0.w, r1.x, r1.y), f3(r1.z, r1.w, r2.x), L.o, L.shear, reach, t, b0, b1, b2) &&
+                  !(flags & RT_SLOT_REJECT_CLOSEST);
+        if (ok) {
+            if (!r.found || t < r.tmax) {
+                r.amb = (r.found && r.tmax <= t * (1.f + RT_FREE_TIE_BAND)) || L.entry > t * (1.f + RT_FREE_TIE_BAND);
+                r.found = true; r.tmax = t; r.hitSlot = slot; r.b0 = b0; r.b1 = b1; r.b2 = b2;
+            } else if (t <= r.tmax * (1.f + RT_FREE_TIE_BAND)) r.amb = true;
+        }
+    }
+    const float reach = r.found ? fminf(r.tmax * (1.f + RT_FREE_CULL_BAND), L.t0) : L.t0;
+    r.have = stack_next_free(reach, st, r.info, r.entry);
     return r;
 }
 

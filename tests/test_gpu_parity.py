@@ -42,8 +42,11 @@ def test_traversal_bit_exact_vs_reference_golden(name, device_scene, gold_dir):
     assert np.array_equal(hit, r["any"])
 
 
+@pytest.mark.parametrize("free", ["0", "1"], ids=["ordered", "orderfree"])
 @pytest.mark.parametrize("name,lo,hi", [("cornell", -1, 6), ("sphere1", -12, 12), ("helmet", 0, 5), ("soup", -5, 105)])
-def test_traversal_bit_exact_vs_oracle_random_rays(name, lo, hi, device_scene, oracle_scene):
+def test_traversal_bit_exact_vs_oracle_random_rays(name, lo, hi, free, device_scene, oracle_scene, monkeypatch):
+    """(orderfree: the batch trace nearest-first, with the rays whose answer the reference's visit order could change replayed in it.)"""
+    monkeypatch.setenv("RT_AMD_FREE_WALK", free)
     param = 200000 if name == "soup" else 0
     rng = np.random.default_rng(123)
     n = 300000
@@ -100,10 +103,13 @@ def test_traversal_full_size_soup(gpu_ctx):
     ds.close(); osc.close(); hs.close()
 
 
+@pytest.mark.parametrize("free", ["0", "1"], ids=["ordered", "orderfree"])
 @pytest.mark.parametrize("name", ["cornell", "sphere1", "helmet"])
-def test_traversal_rays_on_box_planes(name, device_scene, oracle_scene, host_scene):
+def test_traversal_rays_on_box_planes(name, free, device_scene, oracle_scene, host_scene, monkeypatch):
     """Origins ON bounding planes of tree nodes with directions that have zero components: 0 * inf = NaN inside the slab
-    test (geometry.h:895-914).  The device must reject and accept exactly the nodes the reference does."""
+    test (geometry.h:895-914).  The device must reject and accept exactly the nodes the reference does.  (Rays through shared
+    vertices and edges of the mesh are also where two primitives tie: the order-free batch trace must hand those to the ordered walk.)"""
+    monkeypatch.setenv("RT_AMD_FREE_WALK", free)
     ds = device_scene(name)
     nodes, _ = ds.get_bvh(host_scene(name).desc.n_prims)
     rng = np.random.default_rng(7)
@@ -136,6 +142,11 @@ def test_traversal_variants_agree(host_scene, gpu_ctx, monkeypatch):
     tmax = np.full(n, np.inf, np.float32); tmax[:20000] = rng.uniform(0, 30, 20000).astype(np.float32)
     ds = ra.DeviceScene(gpu_ctx, hs.desc_ptr)
     base = ds.trace_closest(o, d, tmax); base_any = ds.trace_any(o, d, tmax)
+    # the batch trace without the reference's visit order (nearest first, near-ties and non-plain rays replayed in that order)
+    monkeypatch.setenv("RT_AMD_FREE_WALK", "1")
+    free = ds.trace_closest(o, d, tmax)
+    monkeypatch.delenv("RT_AMD_FREE_WALK")
+    assert np.array_equal(base[0], free[0]) and np.array_equal(base[1].view(np.uint32), free[1].view(np.uint32)) and np.array_equal(base[2].view(np.uint32), free[2].view(np.uint32))
     monkeypatch.setenv("RT_AMD_EXACT_SLABS", "1")
     alt = ds.trace_closest(o, d, tmax); alt_any = ds.trace_any(o, d, tmax)
     monkeypatch.delenv("RT_AMD_EXACT_SLABS")
@@ -451,7 +462,9 @@ def test_frame_walks_give_identical_images(name, w, device_scene, host_scene, mo
                 {"RT_AMD_FUSE_SHADOW": "0", "RT_AMD_CARRY_FROM": "1000", "RT_AMD_MERGE_MIRROR": "0", "RT_AMD_FRAME_BLOCKS_PER_CU": "4"},
                 # closest hits of the bounce rays by the ordered walk (k_extend_carry) instead of the order-free leaf-box test with replay
                 # (k_extend_flat, trees of at most 32 leaves), and the order-free test for the camera rays too
-                {"RT_AMD_FLAT": "0"}, {"RT_AMD_FLAT_FROM": "0"}, {"RT_AMD_FLAT": "0", "RT_AMD_FINISH": "0"})
+                {"RT_AMD_FLAT": "0"}, {"RT_AMD_FLAT_FROM": "0"}, {"RT_AMD_FLAT": "0", "RT_AMD_FINISH": "0"},
+                # large trees: the persistent-lane closest-hit walk nearest-first instead of in the reference's order, near-ties replayed
+                {"RT_AMD_FREE_PL": "1"})
     for env in variants:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
