@@ -72,6 +72,8 @@ struct DevScene {
     float light_func_int;     // its funcInt
     int n_envs;
     int root_implied;         // the root's box is bit for bit the union of its children's boxes (lane_begin may skip its test for plain rays)
+    const float4 *octs;       // 8 x float4 per record of the eight-wide tree with quantised boxes (rt_oct.h); null when the scene has none
+    int n_octs, oct_stack_cap;
     const float4 *flat;       // 2 x float4 per leaf, in depth-first order: box min xyz, max x | max yz, info word (as in the pair records), -
     int n_flat;               //   present (non-null) only for trees of at most RT_FLAT_MAX leaves whose boxes nest exactly (k_extend_flat)
 };

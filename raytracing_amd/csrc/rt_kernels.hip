@@ -35,6 +35,7 @@
 #include "rt_amd.h"
 #include "rt_device.h"
 #include "rt_traverse2.h"
+#include "rt_oct.h"
 
 #define HIP_OK(expr)                                                                                        \
     do {                                                                                                    \
@@ -221,17 +222,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_batch(DevScene sc, size_t n,
 // FREE (closest hit over quad records only): the order-free walk of rt_traverse2.h; a ray whose answer is not safe against the
 // reference's visit order gets primitive -2 and its index goes on `replay` (replay[0] = count, then the indices), which a second
 // launch of the ordered kernel works through (items / n_items: that launch's indirection).
-template <bool ANY, bool COUNT, bool QUAD, bool FREE = false>
+// OCT (with FREE): the order-free walk over the eight-wide records with quantised boxes (rt_oct.h) instead of the quad records.
+template <bool ANY, bool COUNT, bool QUAD, bool FREE = false, bool OCT = false>
 __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene sc, size_t n, const float *__restrict__ rays, int aos, int *out_prim, float *out_t,
                                                            float *out_b1, float *out_b2, uint8_t *out_any, int *spill, unsigned long long *work, int leaf_min,
                                                            uint32_t *replay = nullptr, const uint32_t *items = nullptr, const uint32_t *n_items = nullptr) {
     static_assert(!FREE || (!ANY && !COUNT && QUAD), "the order-free walk is a closest-hit walk over quad records");
-    constexpr int RING = QUAD ? RT_QUAD_STACK : RT_PAIR_STACK;
+    static_assert(!OCT || FREE, "the eight-wide records serve the order-free walk only");
+    constexpr int RING = OCT ? RT_OCT_STACK : (QUAD ? RT_QUAD_STACK : RT_PAIR_STACK);
     __shared__ int s_si[RING * RT_BLOCK];
     __shared__ float s_st[RING * RT_BLOCK];
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     PairStackT<RING> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
-    st.cap = QUAD ? sc.quad_stack_cap : RT_MAX_STACK;
+    st.cap = OCT ? sc.oct_stack_cap : (QUAD ? sc.quad_stack_cap : RT_MAX_STACK);
     st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     size_t nwaves = nthreads / RT_WAVE, gw = gtid / RT_WAVE;
     const size_t m = n_items ? (size_t)*n_items : n;      // work items: all n rays, or the listed ones
@@ -296,7 +299,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene
         if (leafrun) { const float4 *sl = sc.slots + 3 * (size_t)L.cur; pre[0] = sl[0]; pre[1] = sl[1]; pre[2] = sl[2]; }
 #endif
         float entry = 0.f;
-        if (FREE) { if (walk) lane_walk_quad_free(sc.quads, L, st, info, have, entry); }
+        if (OCT) { if (walk) oct_step_free(sc.octs, L, (uint32_t)L.cur, false, st, info, have, entry); }
+        else if (FREE) { if (walk) lane_walk_quad_free(sc.quads, L, st, info, have, entry); }
         else if (QUAD) {
             if (__ballot(walk && !L.plain) == 0 && !exact_slabs) { if (walk) lane_walk_quad<true>(sc.quads, L, st, info, have); }     // the whole wave takes one version
             else if (walk) lane_walk_quad<false>(sc.quads, L, st, info, have);
@@ -304,9 +308,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene
         if (FREE) {
             if (leafrun) {
 #if RT_LEAF_LOAD_AHEAD
-                LeafOutFree r = lane_leaf_free(sc, sc.slots, L, st, pre);
+                LeafOutFree r = OCT ? oct_leaf_free(sc, sc.slots, L, st, pre) : lane_leaf_free(sc, sc.slots, L, st, pre);
 #else
-                LeafOutFree r = lane_leaf_free(sc, sc.slots, L, st);
+                LeafOutFree r = OCT ? oct_leaf_free(sc, sc.slots, L, st) : lane_leaf_free(sc, sc.slots, L, st);
 #endif
                 L.found = r.found; L.amb = r.amb; L.tmax = r.tmax; L.hitSlot = r.hitSlot; L.b0 = r.b0; L.b1 = r.b1; L.b2 = r.b2;
                 info = r.info; have = r.have; entry = r.entry;
@@ -322,7 +326,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene
         }
         if (fresh) {
             if (FREE) have = lane_begin_free(sc, L, st, po, pd, ptmax); else have = lane_begin<COUNT>(sc, L, st, po, pd, ptmax, nNodes);
-            info = sc.root_info;
+            info = OCT ? 0u : sc.root_info;      // (the root's record is the first of either kind)
+            if (OCT && have && !oct_ray_ok(L)) { L.amb = true; have = false; }      // a reciprocal direction too small or too large for the record-space slab test
         }
         if (walk || leafrun || fresh) { lane_enter(sc, L, info, have); if (FREE) L.entry = entry; }
     }
@@ -2114,7 +2119,7 @@ struct rt_scene {
     std::vector<rt_bvh_node> nodes; std::vector<int32_t> order;
     int n_prims = 0;
     bool classes[RT_NUM_CLASSES] = {};
-    DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_envs, d_light_cdf, d_spill, d_pairs, d_quads, d_flat;
+    DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_envs, d_light_cdf, d_spill, d_pairs, d_quads, d_flat, d_octs;
     int interior_depth = 0;
     std::vector<DevBuf *> d_texels;
     DevBuf d_trace_io, d_work, d_replay;      // d_replay: count + indices of the rays the order-free batch trace hands to the ordered one
@@ -2535,10 +2540,80 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
         }
         HIP_OK(up(sc->d_flat, flat.data(), flat.size() * 4));
     }
+    // Eight-wide records with quantised boxes (rt_oct.h) for the order-free batch trace of large trees: one 128-byte record per interior node
+    // at a depth that is a multiple of three holds its (at most eight) descendants three levels down — or the leaves met on the way — as
+    // 8-bit boxes relative to the node's own box, each containing the descendant's exact box.  Triangle scenes with exactly nested boxes only
+    // (a leaf's exact box is rebuilt from its triangles' vertices when the leaf is tested).
+    std::vector<uint32_t> octs;
+    int n_octs = 0, oct_levels = 0;
+    if (nest_ok && sc->nodes[0].nprim == 0 && d->n_spheres == 0 && nn > 4096 && env_int("RT_AMD_OCT", 1)) {
+        std::vector<int32_t> octIndex(nn, -1);
+        struct Visit { int node, level; };
+        std::vector<Visit> todo; todo.push_back({0, 1});
+        std::vector<int> octNodes;
+        auto entries_of = [&](int r, int *ent) {            // the up-to-eight descendants of interior node r, three levels down
+            int cur[8], ncur = 0, nxt[8], nnxt;
+            cur[ncur++] = r + 1; cur[ncur++] = sc->nodes[r].offset;
+            for (int lvl = 0; lvl < 2; ++lvl) {
+                nnxt = 0;
+                for (int k = 0; k < ncur; ++k) {
+                    const rt_bvh_node &c = sc->nodes[cur[k]];
+                    if (c.nprim != 0) nxt[nnxt++] = cur[k];
+                    else { nxt[nnxt++] = cur[k] + 1; nxt[nnxt++] = c.offset; }
+                }
+                ncur = nnxt; memcpy(cur, nxt, sizeof(int) * ncur);
+            }
+            memcpy(ent, cur, sizeof(int) * ncur);
+            return ncur;
+        };
+        while (!todo.empty()) {
+            Visit v = todo.back(); todo.pop_back();
+            oct_levels = std::max(oct_levels, v.level);
+            octIndex[v.node] = n_octs++; octNodes.push_back(v.node);
+            int ent[8]; int ne = entries_of(v.node, ent);
+            for (int k = ne - 1; k >= 0; --k) if (sc->nodes[ent[k]].nprim == 0) todo.push_back({ent[k], v.level + 1});
+        }
+        octs.assign(32 * (size_t)n_octs, 0u);
+        bool oct_ok = true;
+        for (int oi = 0; oi < n_octs && oct_ok; ++oi) {
+            const int r = octNodes[oi];
+            const rt_bvh_node &R = sc->nodes[r];
+            uint32_t *W = &octs[32 * (size_t)oi];
+            int ent[8]; const int ne = entries_of(r, ent);
+            int ex[3];
+            for (int a = 0; a < 3; ++a) {
+                // smallest power-of-two step with which 255 steps from the node's lower bound reach its upper bound
+                double extent = (double)R.bmax[a] - (double)R.bmin[a];
+                int e = -100;
+                while (e < 100 && 255.0 * std::ldexp(1.0, e) < extent) ++e;
+                ex[a] = e;
+                memcpy(&W[a], &R.bmin[a], 4);
+            }
+            for (int k = 0; k < ne; ++k) {
+                const rt_bvh_node &c = sc->nodes[ent[k]];
+                for (int a = 0; a < 3; ++a) {
+                    // quantised planes, checked in exact (double) arithmetic: origin + q * step <= lo, >= hi
+                    const double o = R.bmin[a], step = std::ldexp(1.0, ex[a]);
+                    int qlo = (int)std::floor(((double)c.bmin[a] - o) / step), qhi = (int)std::ceil(((double)c.bmax[a] - o) / step);
+                    qlo = std::max(0, std::min(255, qlo)); qhi = std::max(0, std::min(255, qhi));
+                    while (qlo > 0 && o + qlo * step > (double)c.bmin[a]) --qlo;
+                    while (qhi < 255 && o + qhi * step < (double)c.bmax[a]) ++qhi;
+                    if (o + qlo * step > (double)c.bmin[a] || o + qhi * step < (double)c.bmax[a]) oct_ok = false;
+                    uint8_t *B = (uint8_t *)&W[4 + 4 * a];
+                    B[2 * k] = (uint8_t)qlo; B[2 * k + 1] = (uint8_t)qhi;
+                }
+                W[16 + k] = c.nprim == 0 ? (uint32_t)octIndex[ent[k]] : childInfo(ent[k]);
+            }
+            W[3] = (uint32_t)(ex[0] + 128) | ((uint32_t)(ex[1] + 128) << 8) | ((uint32_t)(ex[2] + 128) << 16) | ((uint32_t)ne << 24);
+        }
+        if (!oct_ok) { octs.clear(); n_octs = 0; }
+        else HIP_OK(up(sc->d_octs, octs.data(), octs.size() * 4));
+    }
     if (env_int("RT_AMD_NO_QUADS", 0)) quads_ok = false;
     int quad_cap = 3 * (tree_depth / 2 + 1) + 2;      // at most three pushes per record on the path from the root
+    const int oct_cap = n_octs ? 7 * (oct_levels + 1) + 2 : 0;      // ... and seven with eight-wide records
     if (quads_ok) HIP_OK(up(sc->d_quads, quads.data(), quads.size() * 4));
-    size_t spill_ints = (size_t)persistent_grid(ctx) * RT_BLOCK * (size_t)std::max(RT_MAX_STACK, quads_ok ? quad_cap : 0) * 2;
+    size_t spill_ints = (size_t)persistent_grid(ctx) * RT_BLOCK * (size_t)std::max(std::max(RT_MAX_STACK, quads_ok ? quad_cap : 0), oct_cap) * 2;
     HIP_OK(sc->d_spill.alloc(spill_ints * 4));
     sc->spill_bytes = spill_ints * 4;
     DevScene &D = sc->dev;
@@ -2551,6 +2626,7 @@ int rt_scene_create(rt_ctx *this_, const rt_scene_desc *d, rt_scene **out) {
     memcpy(D.root_box, sc->nodes[0].bmin, 12); memcpy(D.root_box + 3, sc->nodes[0].bmax, 12);
     D.root_info = childInfo(0);
     D.quads = quads_ok ? (const float4 *)sc->d_quads.p : nullptr; D.n_quads = quads_ok ? n_quads : 0; D.quad_stack_cap = quad_cap;
+    D.octs = n_octs ? (const float4 *)sc->d_octs.p : nullptr; D.n_octs = n_octs; D.oct_stack_cap = oct_cap;
     D.root_implied = root_implied ? 1 : 0;
     D.flat = flat.empty() ? nullptr : (const float4 *)sc->d_flat.p; D.n_flat = (int)(flat.size() / 8);
     *out = sc.release();
@@ -2573,11 +2649,13 @@ int rt_scene_get_bvh(rt_scene *this_, rt_bvh_node *nodes_out, int32_t *n_nodes_o
     return 0;
 }
 
-// Closest hits of the batch trace through the order-free walk (with the ordered replay of what it flags)?  Needs quad records.  Off unless
-// RT_AMD_FREE_WALK=1: on the 10 M-triangle soup the nearest-first order visits no fewer records than the reference's order by split
-// axis and ray sign does, and the kernel is bound by those fetches (28.4 ms ordered, 29.8 ms order-free, 105 of 16.7 M rays replayed);
-// kept as a cross-check of the order-free primitives that the frame kernels use.
-static bool free_walk_enabled(rt_scene *s) { return s->dev.quads != nullptr && env_int("RT_AMD_FREE_WALK", 0) != 0 && !env_int("RT_AMD_NODE_WALK", 0); }
+// Closest hits of the batch trace through the order-free walk (with the ordered replay of what it flags)?  By default where the scene
+// has eight-wide records (large triangle scenes, rt_oct.h): on the 10 M-triangle soup three tree levels per 128-byte line instead of two
+// bring the launch from 28.4 ms to 21.7 ms (105 of 16.7 M rays replayed).  Over the quad records the nearest-first order alone visits no
+// fewer records than the reference's order by split axis and ray sign (29.8 ms), so scenes without eight-wide records keep the ordered
+// walk unless RT_AMD_FREE_WALK=1 asks for the order-free one (kept as a cross-check of the primitives it shares with the frame kernels).
+// RT_AMD_FREE_WALK=0: the reference's order throughout; RT_AMD_OCT_WALK=0: order-free over quad records.
+static bool free_walk_enabled(rt_scene *s) { return s->dev.quads != nullptr && env_int("RT_AMD_FREE_WALK", s->dev.octs ? 1 : 0) != 0 && !env_int("RT_AMD_NODE_WALK", 0); }
 
 // Batch trace launch: quad records when the scene has them, pair records otherwise and for the counting variant (whose
 // counts are the reference's per-node and per-primitive test counts).
@@ -2593,6 +2671,10 @@ static void launch_trace(rt_scene *this_, int grid, size_t n, const float *rays,
     else if (!ANY && !COUNT && this_->dev.quads && replay) {
         // closest hits without the reference's visit order, then the rays whose answer that order could change, in that order
         (void)hipMemsetAsync(replay, 0, 4, ctx->stream);
+        if (this_->dev.octs && env_int("RT_AMD_OCT_WALK", 1))
+            hipLaunchKernelGGL((k_trace_pairs<false, false, true, true, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
+                               spill, work, tune_leaf_min(), replay, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+        else
         hipLaunchKernelGGL((k_trace_pairs<false, false, true, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
                            spill, work, tune_leaf_min(), replay, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
         hipLaunchKernelGGL((k_trace_pairs<false, false, true>), dim3(std::min(grid, 64)), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,

@@ -52,6 +52,21 @@ struct PairStackT {
         lds_i[k] = info; lds_t[k] = t;
         sp++;
     }
+    // Several pushes at once: reserve(n) moves the oldest ring entries to the spill area until n more fit (n <= RING), put() then writes
+    // entry number `at` (sp .. sp + n - 1) without looking at the ring's fill, and the caller sets sp.
+    __device__ __forceinline__ void reserve(int n) {
+        while (SPILL && sp + n - lo > RING) {
+            if (lo < cap) {
+                int k = (lo & (RING - 1)) * RT_BLOCK;
+                spill_i[(size_t)lo * spill_stride] = lds_i[k]; spill_t[(size_t)lo * spill_stride] = lds_t[k];
+            }
+            lo++;
+        }
+    }
+    __device__ __forceinline__ void put(int at, int info, float t) {
+        int k = (at & (RING - 1)) * RT_BLOCK;
+        lds_i[k] = info; lds_t[k] = t;
+    }
     __device__ __forceinline__ void pop(int &info, float &t) {
         sp--;
         if (SPILL && sp < lo) {
