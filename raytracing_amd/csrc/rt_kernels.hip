@@ -1780,12 +1780,21 @@ enum { RT_WALK_QUADS = 1, RT_WALK_PAIRS = 2 };
 #endif
 
 struct RayArrays { const float *ox, *oy, *oz, *dx, *dy, *dz; };
+#ifdef RT_PHASE_STATS       // diagnostic build only: rounds and busy lanes per phase of trace_share ([0..5] closest hit, [6..11] any hit)
+__device__ unsigned long long g_phase[12];
+extern "C" void rt_debug_phase(unsigned long long *out, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 12);
+    if (reset) { unsigned long long z[12] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z); }
+}
+#endif
 
 // Traverse this wave's chunks of the `total` concatenated positions of a segmented queue; sink(i, L) receives each finished ray
 // (i = its position in the queue arrays).  recs = pair or quad records (LDS or global), slots = leaf slots.
 // FREE (closest hit over quad records): the order-free walk of rt_traverse2.h; the sink sees L.amb on rays that have to be walked again
 // in the reference's order.
-template <bool ANY, int MODE, bool FREE = false, class Stack, class Sink>
+// OCT (with FREE): over the eight-wide records with quantised boxes (rt_oct.h); recs then points at those.
+template <bool ANY, int MODE, bool FREE = false, bool OCT = false, class Stack, class Sink>
 __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *recs, const float4 *slots, RayArrays ra, float tmax0, uint32_t total,
                                             const uint32_t *s_prefix, uint32_t segcap, Stack &st, float *s_ray, Sink sink) {
     const uint32_t lane = lane_id();
@@ -1815,12 +1824,20 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
     uint32_t cur_i = 0, dummy = 0;
     // Every lane is walking, waiting at a leaf, or idle (finished / never started).  Each round the wave runs ONE of the
     // three phases, the one most lanes are waiting for, so the instructions of a phase are issued for a well-filled wave.
+    // Measured on the helmet over the eight-wide records (1440 x 1440, later bounces): 53 % of the rounds walk with 33 lanes on average,
+    // 35 % test leaves with 29, 13 % refill with 36; a ray takes 4.75 steps and 2.75 leaf visits.  Two things that did not help: weighting
+    // the vote by what a round of each phase costs (a refill round is cheap, so run it for fewer lanes: weights 1:1:4 to 2:3:6, frame
+    // 605 -> 606-612 Msamples/s), and two rays per lane, the one that is in the round's phase taking part (rounds -13 %, walking lanes
+    // 33 -> 38, but the exchange of the two register sets and three blocks a CU instead of five: 605 -> 470-535).
     // FREE: a lane that holds a leaf still to be tested need not wait for the leaf phase: the order of the visits is free, so in a walk
     // phase it takes the next record within reach from its stack and expands it, all grandchildren going back on the stack (the leaf's
     // primitives may yet shorten the reach: what was pushed is looked at again when it is popped).  The lanes that wait for the majority's
     // phase thus do work that is needed unless the pending leaf turns out to hold the hit.  A lane whose stack top is another leaf, or
     // empty, cannot walk ahead (spec_blocked) until its leaf has been tested.
     bool spec_blocked = false;
+#ifdef RT_PHASE_STATS
+    unsigned long long ps[6] = {};
+#endif
     while (true) {
         const bool walk = busy && L.mode == RT_LANE_WALK, leaf = busy && L.mode == RT_LANE_LEAF, idle = !busy || L.mode == RT_LANE_DONE;
         const uint64_t im = __ballot(idle);
@@ -1835,6 +1852,9 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
         // nobody has a record of its own to walk, otherwise walkers and lanes walking ahead against the idle lanes
         const bool leaf_phase = FREE && RT_FREE_SPECULATE ? (nL >= RT_FREE_LEAF_MIN || (nW == 0 && nL > 0 && nL >= nI)) : (!(nW >= nL && nW >= nI) && nL >= nI);
         const bool walk_phase = !leaf_phase && (FREE && RT_FREE_SPECULATE ? (nW + nS > 0 && nW + nS >= nI) : (nW >= nL && nW >= nI));
+#ifdef RT_PHASE_STATS
+        if (lane == 0) { if (walk_phase) { ps[0]++; ps[1] += nW; } else if (leaf_phase) { ps[2]++; ps[3] += nL; } else { ps[4]++; ps[5] += nI; } }
+#endif
         if (walk_phase) {
             if (FREE) {
                 uint32_t node = (uint32_t)L.cur; bool step = walk;
@@ -1845,7 +1865,7 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
                         else { node = e; step = true; }
                     } else spec_blocked = true;
                 }
-                if (step) quad_step_free(recs, L, node, !walk, st, info, have, entry);
+                if (step) { if (OCT) oct_step_free(recs, L, node, !walk, st, info, have, entry); else quad_step_free(recs, L, node, !walk, st, info, have, entry); }
             }
             else if (MODE == RT_WALK_QUADS) {
                 if (__ballot(walk && !L.plain) == 0) { if (walk) lane_walk_quad<true, ANY>(recs, L, st, info, have); }     // the whole wave takes one version
@@ -1858,7 +1878,7 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
         } else if (leaf_phase) {
             if (FREE) {
                 if (leaf) {
-                    LeafOutFree r = lane_leaf_free(sc, slots, L, st);
+                    LeafOutFree r = OCT ? oct_leaf_free<ANY>(sc, slots, L, st) : lane_leaf_free(sc, slots, L, st);
                     L.found = r.found; L.amb = r.amb; L.tmax = r.tmax; L.hitSlot = r.hitSlot; L.b0 = r.b0; L.b1 = r.b1; L.b2 = r.b2;
                     info = r.info; have = r.have; entry = r.entry;
                     spec_blocked = false;
@@ -1887,23 +1907,27 @@ __device__ __forceinline__ void trace_share(const DevScene &sc, const float4 *re
                 cur_i = __float_as_uint(s_ray[6 * RT_WAVE + k]);
                 busy = true; moved = true;
                 if (FREE) have = lane_begin_free(sc, L, st, po, pd, tmax0); else have = lane_begin<false>(sc, L, st, po, pd, tmax0, dummy);
-                info = sc.root_info;
+                info = OCT ? 0u : sc.root_info;
+                if (OCT && have && !oct_ray_ok(L)) { L.amb = true; have = false; }
             }
             rd += take; avail -= take;
         }
         if (moved) { lane_enter(sc, L, info, have); if (FREE) L.entry = entry; }
     }
     if (busy && L.mode == RT_LANE_DONE) sink(cur_i, L);
+#ifdef RT_PHASE_STATS
+    if (lane == 0) for (int k = 0; k < 6; ++k) atomicAdd(&g_phase[(ANY ? 6 : 0) + k], ps[k]);
+#endif
 }
 
-template <int MODE, bool FREE = false>
+template <int MODE, bool FREE = false, bool OCT = false>
 __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend_pl(DevScene sc, RenderParams rp, int bounce, PathQueue q, HitBuf hb, uint32_t *cls_list, uint32_t cap,
                                                          uint32_t segcap, float4 *lbuf, BounceCounts *counts, BounceStats *stats, int *spill) {
     __shared__ int s_si[RT_FRAME_RING * RT_BLOCK];
     __shared__ float s_st[RT_FRAME_RING * RT_BLOCK];
     __shared__ float s_rays[(RT_BLOCK / RT_WAVE) * 7 * RT_WAVE];
     __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE], s_cls[RT_NUM_CLASSES];
-    const float4 *recs = MODE == RT_WALK_QUADS ? sc.quads : sc.pairs, *slots = sc.slots;
+    const float4 *recs = OCT ? sc.octs : (MODE == RT_WALK_QUADS ? sc.quads : sc.pairs), *slots = sc.slots;
     BounceCounts *bc = counts + bounce;
     if (threadIdx.x < RT_NUM_CLASSES) s_cls[threadIdx.x] = 0;
     const uint32_t total = segment_prefix(bc->queue, s_prefix, s_wave);
@@ -1912,14 +1936,14 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend_pl(DevScene sc, RenderPa
     if (threadIdx.x == 0) { bc->shadow[blockIdx.x] = 0; counts[bounce + 1].queue[blockIdx.x] = 0; }
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     PairStackT<RT_FRAME_RING> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
-    st.cap = MODE == RT_WALK_QUADS ? sc.quad_stack_cap : RT_MAX_STACK;
+    st.cap = OCT ? sc.oct_stack_cap : (MODE == RT_WALK_QUADS ? sc.quad_stack_cap : RT_MAX_STACK);
     st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     RayArrays ra = {q.ox, q.oy, q.oz, q.dx, q.dy, q.dz};
-    trace_share<false, MODE, FREE>(sc, recs, slots, ra, RT_INF, total, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE],
-                             [&](uint32_t i, const LaneTrav &L) {
-                                 // (order-free walk: -2 marks a ray the second sweep walks again in the reference's order)
-                                 hb.slot[i] = (FREE && L.amb) ? -2 : (L.found ? L.hitSlot : -1); hb.t[i] = L.tmax; hb.b0[i] = L.b0; hb.b1[i] = L.b1; hb.b2[i] = L.b2;
-                             });
+    auto sink = [&](uint32_t i, const LaneTrav &L) {
+        // (order-free walk: -2 marks a ray the second sweep walks again in the reference's order)
+        hb.slot[i] = (FREE && L.amb) ? -2 : (L.found ? L.hitSlot : -1); hb.t[i] = L.tmax; hb.b0[i] = L.b0; hb.b1[i] = L.b1; hb.b2[i] = L.b2;
+    };
+    trace_share<false, MODE, FREE, OCT>(sc, recs, slots, ra, RT_INF, total, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE], sink);
     __threadfence_block();
     __syncthreads();
     uint32_t n_replayed = 0;
@@ -1986,27 +2010,30 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_extend_pl(DevScene sc, RenderPa
     if (FREE && n_replayed) atomicAdd(&stats[bounce].n_replay, n_replayed);      // statistics only
 }
 
-template <int MODE>
+// OCT: the any-hit walk over the eight-wide records with quantised boxes (rt_oct.h; the order of IntersectP's visits is free anyway, and the
+// leaves are tested only behind their exact boxes); rays the record-space slab test cannot take (zero, tiny or huge reciprocal direction
+// components) are marked 2 and walked over the quad records in the second sweep.
+template <int MODE, bool OCT = false>
 __global__ __launch_bounds__(RT_BLOCK, 5) void k_shadow_pl(DevScene sc, int bounce, ShadowQueue sq, int *occluded, uint32_t segcap, float4 *lbuf, BounceCounts *counts,
                                                          BounceStats *stats, int *spill) {
     __shared__ int s_si[RT_FRAME_RING * RT_BLOCK];
     __shared__ float s_st[RT_FRAME_RING * RT_BLOCK];
     __shared__ float s_rays[(RT_BLOCK / RT_WAVE) * 7 * RT_WAVE];
     __shared__ uint32_t s_prefix[RT_SEG_BLOCKS + 1], s_wave[RT_BLOCK / RT_WAVE];
-    const float4 *recs = MODE == RT_WALK_QUADS ? sc.quads : sc.pairs, *slots = sc.slots;
+    const float4 *recs = OCT ? sc.octs : (MODE == RT_WALK_QUADS ? sc.quads : sc.pairs), *slots = sc.slots;
     BounceCounts *bc = counts + bounce;
     const uint32_t total = segment_prefix(bc->shadow, s_prefix, s_wave);
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[bounce].n_shadow += total;      // (one launch per light and bounce when every light is sampled)
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     PairStackT<RT_FRAME_RING> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
-    st.cap = MODE == RT_WALK_QUADS ? sc.quad_stack_cap : RT_MAX_STACK;
+    st.cap = OCT ? sc.oct_stack_cap : (MODE == RT_WALK_QUADS ? sc.quad_stack_cap : RT_MAX_STACK);
     st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     RayArrays ra = {sq.ox, sq.oy, sq.oz, sq.dx, sq.dy, sq.dz};
     // tMax = 1 - ShadowEpsilon (interaction.h SpawnRayTo)
     // (Deferring the leaves here as trace_any_deferred_quads does was measured on the helmet: 0.235 s against 0.237 s for the frame's shadow rays — lanes
     // that refill gain from the early exit of an occluded ray, and the phase vote already keeps them busy.)
-    trace_share<true, MODE>(sc, recs, slots, ra, 1.f - 0.0001f, total, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE],
-                            [&](uint32_t i, const LaneTrav &L) { occluded[i] = L.found ? 1 : 0; });
+    auto sink = [&](uint32_t i, const LaneTrav &L) { occluded[i] = (OCT && L.amb) ? 2 : (L.found ? 1 : 0); };
+    trace_share<true, MODE, OCT, OCT>(sc, recs, slots, ra, 1.f - 0.0001f, total, s_prefix, segcap, st, &s_rays[(threadIdx.x / RT_WAVE) * 7 * RT_WAVE], sink);
     __threadfence_block();
     __syncthreads();
     uint32_t seg = 0;
@@ -2016,7 +2043,13 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_shadow_pl(DevScene sc, int boun
         if (g >= total) break;
         while (g >= s_prefix[seg + 1]) seg++;
         uint32_t i = seg * segcap + (g - s_prefix[seg]);
-        if (!occluded[i]) {
+        int occ = occluded[i];
+        if (OCT && occ == 2) {
+            LaneTrav R = {};
+            trace_one<true, 1, true>(sc, sc.quads, sc.slots, f3(sq.ox[i], sq.oy[i], sq.oz[i]), f3(sq.dx[i], sq.dy[i], sq.dz[i]), 1.f - 0.0001f, st, R);
+            occ = R.found ? 1 : 0;
+        }
+        if (!occ) {
             uint32_t id = sq.id[i];
             float4 Lr = lbuf[id];
             Lr.x += sq.cr[i]; Lr.y += sq.cg[i]; Lr.z += sq.cb[i];
@@ -2989,11 +3022,13 @@ static int render_lane(rt_scene *this_, RenderLane &ln, const rt_camera *cam, co
     const bool use_flat = lds_scene && round_pairs && !frame_old && this_->dev.flat != nullptr && env_int("RT_AMD_FLAT", 1) != 0;
     const int flat_from = env_int("RT_AMD_FLAT_FROM", 1);
     // later bounces on large trees: the persistent-lane walk without the reference's visit order (near-ties walked again in that order).
-    // Off unless RT_AMD_FREE_PL=1.  Measured on the helmet, 1440 x 1440 @ 64 spp: nearest-first order alone 575 Msamples/s against 574 in the
-    // reference's order (7 rays in 100 000 replayed) — the split-axis order is as good a guess at "near" as the entry distances; with lanes
-    // that hold an untested leaf walking ahead (RT_FREE_SPECULATE, leaves tested once 8 / 16 / 32 / 48 lanes hold one): 496 / 524 / 540 / 512.
-    // The records fetched ahead are wasted whenever the pending leaf holds the hit, and they cost L1 room and LDS stack traffic.
-    const bool free_pl = env_int("RT_AMD_FREE_PL", 0) != 0;
+    // On where the scene has the eight-wide records (RT_AMD_FREE_PL=0 turns it off, =1 forces it over the quad records too).  Measured on the
+    // helmet, 1440 x 1440 @ 64 spp: over the eight-wide records 597 Msamples/s against 569 in the reference's order over the quad records
+    // (MetalRoughSpheres 2820 against 2725; 7 rays in 100 000 replayed, images identical).  Over the quad records nearest-first order alone
+    // gives 575 against 574 — the split-axis order is as good a guess at "near" as the entry distances — and with lanes that hold an untested
+    // leaf walking ahead (RT_FREE_SPECULATE, leaves tested once 8 / 16 / 32 / 48 lanes hold one): 496 / 524 / 540 / 512: the records fetched
+    // ahead are wasted whenever the pending leaf holds the hit, and they cost L1 room and LDS stack traffic.
+    const bool free_pl = env_int("RT_AMD_FREE_PL", this_->dev.octs ? 1 : 0) != 0;
     // shadow rays traced inside the shading kernels: scenes whose tree and tables both sit in LDS
     // (only while five blocks of the fused kernel still share a CU's 160 KB of LDS: 25.6 KB static + the scene's tables <= 32 KB)
     const bool all_in_lds = lds_scene && round_pairs && !frame_old && shade_tables_in_lds(this_->dev) && shade_lds_bytes(this_->dev) <= 6400 && !this_->dev.envs;
@@ -3042,7 +3077,10 @@ static int render_lane(rt_scene *this_, RenderLane &ln, const rt_camera *cam, co
                 else
                     hipLaunchKernelGGL(k_extend<false>, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, rp, b, q[cq], hb, (uint32_t *)ln.d_cls.p,
                                        ucap, useg, lbuf, counts, bstats, ln.spill, round_quads | rr_extend);
-            } else if (walk_mode == RT_WALK_QUADS && free_pl)
+            } else if (walk_mode == RT_WALK_QUADS && free_pl && this_->dev.octs && env_int("RT_AMD_OCT_PL", 1))
+                hipLaunchKernelGGL((k_extend_pl<RT_WALK_QUADS, true, true>), dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, rp, b, q[cq], hb,
+                                   (uint32_t *)ln.d_cls.p, ucap, useg, lbuf, counts, bstats, ln.spill);
+            else if (walk_mode == RT_WALK_QUADS && free_pl)
                 hipLaunchKernelGGL((k_extend_pl<RT_WALK_QUADS, true>), dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, rp, b, q[cq], hb,
                                    (uint32_t *)ln.d_cls.p, ucap, useg, lbuf, counts, bstats, ln.spill);
             else if (walk_mode == RT_WALK_QUADS)
@@ -3082,7 +3120,10 @@ static int render_lane(rt_scene *this_, RenderLane &ln, const rt_camera *cam, co
                         else
                             hipLaunchKernelGGL(k_shadow<false>, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, b, sq, useg, lbuf, counts, bstats,
                                                ln.spill, round_quads | rr_shadow);
-                    } else if (walk_mode == RT_WALK_QUADS)       // the hit buffer's slot array is free once the shading kernels are done
+                    } else if (walk_mode == RT_WALK_QUADS && this_->dev.octs && env_int("RT_AMD_OCT_SHADOW", 1))
+                        hipLaunchKernelGGL((k_shadow_pl<RT_WALK_QUADS, true>), dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, b, sq, hb.slot, useg, lbuf,
+                                           counts, bstats, ln.spill);
+                    else if (walk_mode == RT_WALK_QUADS)       // the hit buffer's slot array is free once the shading kernels are done
                         hipLaunchKernelGGL(k_shadow_pl<RT_WALK_QUADS>, dim3(nseg), dim3(RT_BLOCK), 0, ln.stream, this_->dev, b, sq, hb.slot, useg, lbuf,
                                            counts, bstats, ln.spill);
                     else

@@ -119,7 +119,10 @@ __device__ __forceinline__ void oct_step_free(const float4 *octs, const LaneTrav
 
 // The pending leaf of the eight-wide walk: its exact box first (the union of its triangles' bounds, min / max of the vertices), then, if the
 // ray enters that box within reach, its primitives as in lane_leaf_free.
-template <class Stack>
+// ANY: BVHAccel::IntersectP (bvh.cpp:284-320) — the ray's tMax is fixed, the first primitive hit ends the walk, and nothing depends on the
+// order of the visits (so no tie can arise and the flag is left alone): the answer is whether any primitive of any leaf whose exact box the
+// ray enters before tMax is hit.
+template <bool ANY = false, class Stack>
 __device__ __forceinline__ LeafOutFree oct_leaf_free(const DevScene &sc, const float4 *slots, const LaneTrav &L, Stack &st, const float4 *first = nullptr) {
     LeafOutFree r; r.found = L.found; r.amb = L.amb; r.tmax = L.tmax; r.hitSlot = L.hitSlot; r.b0 = L.b0; r.b1 = L.b1; r.b2 = L.b2;
     float reach = free_reach(L);
@@ -143,11 +146,12 @@ __device__ __forceinline__ LeafOutFree oct_leaf_free(const DevScene &sc, const f
             float4 r0 = k0, r1 = k1, r2 = k2;
             if (i > 0) { const float4 *s = slots + 3 * (size_t)slot; r0 = s[0]; r1 = s[1]; r2 = s[2]; }
             const uint32_t flags = __float_as_uint(r2.y);
-            reach = r.found ? fminf(r.tmax * (1.f + RT_FREE_CULL_BAND), L.t0) : L.t0;
+            reach = (!ANY && r.found) ? fminf(r.tmax * (1.f + RT_FREE_CULL_BAND), L.t0) : L.t0;
             float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
             const bool ok = triangle_test_sheared(f3(r0.x, r0.y, r0.z), f3(r0.w, r1.x, r1.y), f3(r1.z, r1.w, r2.x), L.o, L.shear, reach, t, b0, b1, b2) &&
-                            !(flags & RT_SLOT_REJECT_CLOSEST);
-            if (ok) {
+                            (ANY || !(flags & RT_SLOT_REJECT_CLOSEST));
+            if (ANY) { if (ok) { r.found = true; break; } }
+            else if (ok) {
                 if (!r.found || t < r.tmax) {
                     r.amb = (r.found && r.tmax <= t * (1.f + RT_FREE_TIE_BAND)) || entry > t * (1.f + RT_FREE_TIE_BAND);
                     r.found = true; r.tmax = t; r.hitSlot = slot; r.b0 = b0; r.b1 = b1; r.b2 = b2;
@@ -155,7 +159,8 @@ __device__ __forceinline__ LeafOutFree oct_leaf_free(const DevScene &sc, const f
             }
         }
     }
-    reach = r.found ? fminf(r.tmax * (1.f + RT_FREE_CULL_BAND), L.t0) : L.t0;
+    if (ANY && r.found) { r.have = false; r.info = 0; r.entry = 0.f; return r; }
+    reach = (!ANY && r.found) ? fminf(r.tmax * (1.f + RT_FREE_CULL_BAND), L.t0) : L.t0;
     r.have = stack_next_free(reach, st, r.info, r.entry);
     return r;
 }

@@ -441,7 +441,7 @@ def test_full_size_frames_against_reference(name, w, h, sx, sy, gw, gh, gspp, de
 
 
 @pytest.mark.parametrize("name,w", [("cornell", 200), ("cornell_plastic", 120), ("cornell_metal", 120), ("cornell_roughglass", 120), ("cornell_env", 120), ("helmet", 160), ("spheres2", 160),
-                                    ("spheres_env", 120)])
+                                    ("spheres_env", 120), ("mrspheres", 120)])
 def test_frame_walks_give_identical_images(name, w, device_scene, host_scene, monkeypatch):
     """The frame kernels have three walks (round-based over pair/quad records, persistent lanes, round-based over plain
     nodes) and several ways of dividing and fusing the work.  Traversal is bit-exact in all of them and every sample is a pure
@@ -463,8 +463,11 @@ def test_frame_walks_give_identical_images(name, w, device_scene, host_scene, mo
                 # closest hits of the bounce rays by the ordered walk (k_extend_carry) instead of the order-free leaf-box test with replay
                 # (k_extend_flat, trees of at most 32 leaves), and the order-free test for the camera rays too
                 {"RT_AMD_FLAT": "0"}, {"RT_AMD_FLAT_FROM": "0"}, {"RT_AMD_FLAT": "0", "RT_AMD_FINISH": "0"},
-                # large trees: the persistent-lane closest-hit walk nearest-first instead of in the reference's order, near-ties replayed
-                {"RT_AMD_FREE_PL": "1"})
+                # large trees: the persistent-lane closest-hit walk in the reference's order over the quad records; nearest-first with
+                # near-ties replayed over the quad records instead of the eight-wide ones (scenes without the latter: over the quad records
+                # instead of in the reference's order); the any-hit walk over the quad records in the reference's order
+                {"RT_AMD_FREE_PL": "0"}, {"RT_AMD_FREE_PL": "1", "RT_AMD_OCT_PL": "0"}, {"RT_AMD_OCT_SHADOW": "0"},
+                {"RT_AMD_FREE_PL": "0", "RT_AMD_OCT_SHADOW": "0", "RT_AMD_FRAME_ROUND_BOUNCES": "0"})
     for env in variants:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -476,10 +479,11 @@ def test_frame_walks_give_identical_images(name, w, device_scene, host_scene, mo
 
 
 @pytest.mark.parametrize("name,w,ordered", [("cornell", 800, {"RT_AMD_SHADOW_CARRY_FROM": "0"}), ("cornell", 800, {"RT_AMD_FRAME_NODE_WALK": "1", "RT_AMD_ROUND_PAIRS": "0"}),
-                                            ("helmet", 720, {"RT_AMD_FRAME_ROUND_BOUNCES": "0"}), ("cornell_env", 400, {"RT_AMD_SHADOW_CARRY_FROM": "0"})])
+                                            ("helmet", 720, {"RT_AMD_FRAME_ROUND_BOUNCES": "0", "RT_AMD_OCT_SHADOW": "0"}), ("cornell_env", 400, {"RT_AMD_SHADOW_CARRY_FROM": "0"})])
 def test_deferred_shadow_walks_answer_as_the_ordered_walks(name, w, ordered, device_scene, host_scene, monkeypatch):
     """Shadow rays of the round-based kernels visit the interior nodes first and the leaves afterwards (their tMax is fixed, so the
-    order of BVHAccel::IntersectP is free); the persistent-lane kernels, k_shadow_carry and the node walk keep the reference's order.
+    order of BVHAccel::IntersectP is free), and so do those of the persistent-lane kernel over the eight-wide records; the persistent-lane
+    kernel over the quad records, k_shadow_carry and the node walk keep the reference's order.
     Ten million paths and more: one differing any-hit answer would change a radiance sum, so the images must be identical to the
     last bit and the ray counts equal."""
     ds = device_scene(name)
