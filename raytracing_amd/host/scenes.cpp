@@ -4,7 +4,7 @@
 // Scene contents follow the reference's scene functions (RayTracing/RayTracing.cpp):
 //   "cornell"   Cornellbox()      :46-192
 //   "sphere1"   sphere1()         :344-408
-//   "helmet"    DamagedHelmet()   :218-316
+//   "helmet"    DamagedHelmet()   :218-316   ("helmet_grey": the same with a room of albedo 0.8, a test scene)
 //   "mrspheres" MetalRoughSphere() :194-216 (the model's geometry buffer is absent from the reference; see BuildMRSpheres)
 //   "spheres2"  sphere1() plus a GlassMaterial sphere and an earth-textured sphere
 //               (the Lambertian / metal / dielectric + earthmap configuration)
@@ -213,9 +213,10 @@ void BuildSpheres(BuiltScene &bs, bool extended, const std::string &assets, bool
     bs.lookat = LookAt(Point3f(13, 2, 3), Point3f(0.f, 0.f, 0.f), Vector3f(0.0f, 1.0f, 0.0f));
 }
 
-void BuildHelmet(BuiltScene &bs, const std::string &assets, const std::string &model = "/DamagedHelmet/glTF/DamagedHelmet.gltf") {
+// room_albedo: the reference's room is white (1); "helmet_grey" takes 0.8, so that no throughput sits exactly on Li's roulette threshold
+void BuildHelmet(BuiltScene &bs, const std::string &assets, const std::string &model = "/DamagedHelmet/glTF/DamagedHelmet.gltf", Float room_albedo = 1.0f) {
     std::vector<std::shared_ptr<Primitive>> prims; std::vector<std::shared_ptr<Light>> lights;
-    std::shared_ptr<Material> m1 = Matte(Spectrum(1.0f, 1.0f, 1.0f));
+    std::shared_ptr<Material> m1 = Matte(Spectrum(room_albedo, room_albedo, room_albedo));
     AddCeilingLight(bs, prims, lights, m1, 25.f);
     Float L = 5;
     auto room = BoxTriangles(bs, Transform(), 10, L, L, L);
@@ -303,6 +304,7 @@ rth_scene *rth_scene_build(const char *name, const char *assets_dir, int64_t par
         else if (nm == "spheres_env") BuildSpheres(h->b, true, assets, false, true);
         else if (nm == "helmet") BuildHelmet(h->b, assets);
         else if (nm == "helmet_glb") BuildHelmet(h->b, assets, "/DamagedHelmet/glTF-Binary/DamagedHelmet.glb");   // the same model as one binary container
+        else if (nm == "helmet_grey") BuildHelmet(h->b, assets, "/DamagedHelmet/glTF/DamagedHelmet.gltf", 0.8f);
         else if (nm == "mrspheres") BuildMRSpheres(h->b, assets);
         else if (nm == "soup") BuildSoup(h->b, param);
         else throw std::runtime_error("unknown scene '" + nm + "'");

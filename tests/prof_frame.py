@@ -1,4 +1,5 @@
 """Small driver for profiling: render one scene through the C ABI.  usage: prof_frame.py scene width sx sy [pool] [repeats]
+(PROF_HEIGHT in the environment: a frame that is not square)
 One warm-up render at 1/4 of the samples (kernel code upload, workspace allocation), then `repeats` timed renders; prints the best."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,8 +7,12 @@ import raytracing_amd as ra
 name, w, sx, sy = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 pool = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 reps = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+h = int(os.environ.get("PROF_HEIGHT", w))
+if name == "mrspheres":
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mrspheres_bin; mrspheres_bin.ensure(ra.default_assets_dir())
 ctx = ra.Context(0); s = ra.HostScene(name); ds = ra.DeviceScene(ctx, s.desc_ptr)
-cam = s.camera(w, w)
+cam = s.camera(w, h)
 if reps > 1:
     ds.render_device(cam, ra.make_opts(sx, sy, pool_paths=pool))
 best = None

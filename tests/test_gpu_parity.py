@@ -302,7 +302,7 @@ _EST_FLAGS = {1: capi.RT_RENDER_LI, 2: capi.RT_RENDER_ALL_LIGHTS, 3: capi.RT_REN
 
 
 @pytest.mark.parametrize("est,name", [(1, "cornell"), (1, "cornell_env"), (1, "spheres_env"), (1, "spheres2"), (1, "helmet"), (2, "cornell_metal"), (2, "helmet"),
-                                      (3, "cornell_env"), (3, "cornell")])
+                                      (3, "cornell_env"), (3, "cornell"), (1, "helmet_grey"), (3, "helmet_grey")])
 def test_other_estimators_match_oracle_per_pixel(est, name, device_scene, oracle_scene, host_scene):
     """PathIntegrator::Li (1) and UniformSampleAllLights inside the recursive (2) and the iterative (3) estimator, same sampler on both
     sides: same ray counts and per-pixel sums as the oracle.  spheres2 has a glass sphere (etaScale) and no light: Li sees no sky, so
@@ -311,6 +311,8 @@ def test_other_estimators_match_oracle_per_pixel(est, name, device_scene, oracle
     # The helmet stands on surfaces of albedo 1: a diffuse bounce multiplies the throughput by f cos / pdf = 1 up to rounding, so under
     # Li's default rrThreshold of 1 the test 'max(throughput) < rrThreshold' is decided by the last bit (device and host sine / cosine
     # differ there) and one path in 3000 takes the other side: 5 % roulette or none.  Away from that value the two sides agree.
+    # "helmet_grey" is the same scene with a room of albedo 0.8: no throughput sits on the threshold, so it runs at the default 1 and is
+    # held to the floor of the other scenes.
     rr = 0.8 if (name == "helmet" and est in (1, 3)) else 1.0
     opts = ra.make_opts(4, 4, flags=_EST_FLAGS[est], rr_threshold=rr)
     img, st = device_scene(name).render(cam, opts)
