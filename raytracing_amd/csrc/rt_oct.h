@@ -1,4 +1,5 @@
-// rt_oct.h — closest hit over eight-wide records with quantised boxes, for the order-free batch trace of large trees.
+// rt_oct.h — closest hit (and any hit) over eight-wide records with quantised boxes, for the order-free walks of large trees: the batch trace
+// (k_trace_pairs) and the persistent-lane kernels of the frame (k_extend_pl, k_shadow_pl).
 //
 // The batch trace of incoherent rays through a tree that does not fit the caches is bound by the number of 128-byte lines it fetches, and
 // once the visit order of BVHAccel::Intersect (bvh.cpp:247-282) is given up (rt_traverse2.h: nearest first, near-ties replayed in the
