@@ -236,6 +236,67 @@ def test_root_box_tighter_than_its_children(host_scene, gpu_ctx):
     ds.close(); osc.close()
 
 
+def test_order_free_walks_on_tied_geometry(host_scene, gpu_ctx, monkeypatch):
+    """Geometry made of ties: a grid of triangles that share edges and vertices exactly, every triangle a second time with the same
+    vertices, the same grid again shifted by half a cell in its own plane, and once more a millionth of the distance behind.  Rays aimed
+    at vertices, edge midpoints and random points of the grid, a quarter of them axis-parallel.  Which of several primitives with
+    (nearly) the same t BVHAccel::Intersect returns is decided by its visit order (bvh.cpp:247-282, triangle.cpp:104-111); the
+    order-free walks must notice every such ray and hand it to the ordered walk: same primitive, same bits as the oracle, and as the
+    ordered walk on the device."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    import oracle_lib as ol
+    nx, ny = 60, 50
+    xs, ys = np.meshgrid(np.arange(nx + 1, dtype=np.float32), np.arange(ny + 1, dtype=np.float32), indexing="ij")
+
+    def layer(dx, z):
+        P = np.stack([xs + np.float32(dx), ys, np.full_like(xs, z)], axis=-1)
+        a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+        return np.concatenate([np.stack([a, b, c], axis=2).reshape(-1, 3, 3), np.stack([a, c, d], axis=2).reshape(-1, 3, 3)])
+    base = layer(0, 10)
+    tris = np.concatenate([base, base, layer(0.5, 10), layer(0, np.float32(10) * np.float32(1 + 1e-6))]).astype(np.float32)
+    n_tris = len(tris)
+    hs = host_scene("soup", n_tris)
+    d = type(hs.desc).from_buffer_copy(hs.desc)
+    flat = np.ascontiguousarray(tris.reshape(-1))
+    d.tri_p = flat.ctypes.data_as(C.POINTER(C.c_float))
+    nodes, order = ra.bvh_build(ra.prim_bounds(C.pointer(d)))
+    d.n_nodes = len(nodes); d.bvh_nodes = nodes.ctypes.data_as(C.POINTER(ra.capi.BvhNode)); d.prim_order = order.ctypes.data_as(C.POINTER(C.c_int32))
+    assert len(nodes) > 4096                                       # large enough for the eight-wide records
+    ds = ra.DeviceScene(gpu_ctx, C.pointer(d)); osc = ol.OracleScene(C.pointer(d))
+    rng = np.random.default_rng(11)
+    n = 240000
+    o = np.stack([rng.uniform(-5, nx + 5, n), rng.uniform(-5, ny + 5, n), rng.uniform(0, 6, n)], axis=1).astype(np.float32)
+    k = n // 4
+    target = np.empty((n, 3), np.float32)
+    target[:k] = np.stack([rng.integers(0, nx + 1, k), rng.integers(0, ny + 1, k), np.full(k, 10)], axis=1)                    # vertices
+    target[k:2 * k] = np.stack([rng.integers(0, nx, k) + 0.5, rng.integers(0, ny + 1, k), np.full(k, 10)], axis=1)             # edge midpoints
+    target[2 * k:] = np.stack([rng.uniform(0, nx, n - 2 * k), rng.uniform(0, ny, n - 2 * k), np.full(n - 2 * k, 10)], axis=1)  # anywhere
+    dd = (target - o).astype(np.float32)
+    o[3 * k:, :2] = target[3 * k:, :2]; dd[3 * k:] = [0, 0, 1]                                                                  # straight up
+    o[3 * k: 3 * k + k // 2, :2] = np.round(o[3 * k: 3 * k + k // 2, :2])                                                      # ... through vertices
+    tmax = np.full(n, np.inf, np.float32)
+    p2, t2, b2, _, _ = osc.trace_closest(o, dd, tmax)
+    assert (p2 >= 0).mean() > 0.9
+    for free in ("1", "0"):
+        monkeypatch.setenv("RT_AMD_FREE_WALK", free)
+        prim, t, b = ds.trace_closest(o, dd, tmax)
+        assert np.array_equal(prim, p2) and np.array_equal(t.view(np.uint32), t2.view(np.uint32)), free
+        assert np.array_equal(b[prim >= 0].view(np.uint32), b2[p2 >= 0].view(np.uint32)), free
+    monkeypatch.setenv("RT_AMD_FREE_WALK", "1")
+    rays = torch.from_numpy(np.concatenate([o.T, dd.T, tmax[None]], axis=0).copy()).cuda().contiguous()
+    hits = torch.empty((4, n), dtype=torch.float32, device="cuda")
+    st = ds.trace_closest_device(n, rays.data_ptr(), hits.data_ptr(), repeats=1)
+    torch.cuda.synchronize()
+    assert np.array_equal(hits[0].view(torch.int32).cpu().numpy(), p2)
+    assert st.rays_replayed > n // 2                               # nearly every hit here has a rival within the band
+    far = np.where(p2 >= 0, t2 * np.float32(1.00001), np.float32(50)).astype(np.float32)
+    near = np.where(p2 >= 0, t2 * np.float32(0.99999), np.float32(50)).astype(np.float32)
+    for tm in (far, near):
+        assert np.array_equal(ds.trace_any(o, dd, tm), osc.trace_any(o, dd, tm))
+    ds.close(); osc.close()
+
+
 def test_trace_edge_cases(device_scene):
     ds = device_scene("cornell")
     e = np.zeros((0, 3), np.float32)
