@@ -125,6 +125,10 @@ def traversal_roofline(ctx, n_tris, n_rays, repeats, bounces=4, ray_slice=None):
            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch (PMC, %s)" % traffic_src if traffic else None,
            "traffic_note": None if traffic else (("%s was measured on another build of librt_amd.so" % stale) if stale else "no PMC summary for this workload"),
            "real_hbm_gbs": round(traffic / seconds / 1e9, 1) if traffic else None,
+           "real_hbm_frac": round(traffic / seconds / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+           "traffic_over_algorithmic": round(traffic / bytes_per_launch, 4) if traffic else None,
+           "frac_note": "achieved counts the bytes of the reference's own walk (32 B per node it slab-tests, 36 B per triangle it tests); the timed kernel reaches the same "
+                        "answers through three tree levels per 128-byte line and fetches traffic_over_algorithmic of those bytes, so frac may pass 1 while real_hbm_frac stays below it",
            "algorithmic_bytes_per_launch": bytes_per_launch,
            "workload": "%d-triangle soup, %d incoherent rays" % (n_tris, n_rays),
            "bytes_per_ray": round(bytes_per_launch / n_rays, 1), "nodes_per_ray": round(nodes / n_rays, 2), "tris_per_ray": round(tests / n_rays, 2),

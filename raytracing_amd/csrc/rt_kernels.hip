@@ -216,17 +216,22 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_batch(DevScene sc, size_t n,
 #ifndef RT_LEAF_LOAD_AHEAD
 #define RT_LEAF_LOAD_AHEAD 1
 #endif
+#ifndef RT_TRACE_RUN
+#define RT_TRACE_RUN 256        // rays a wave of the order-free batch trace draws at a time
+#endif
 #ifndef RT_TRACE_OCC
 #define RT_TRACE_OCC 4          // waves per SIMD the batch trace kernels are compiled for (they are launched four blocks to a CU: five lose to L2 thrash)
 #endif
 // FREE (closest hit over quad records only): the order-free walk of rt_traverse2.h; a ray whose answer is not safe against the
-// reference's visit order gets primitive -2 and its index goes on `replay` (replay[0] = count, then the indices), which a second
-// launch of the ordered kernel works through (items / n_items: that launch's indirection).
+// reference's visit order is walked again at once, by the lane that holds it, in that order over the quad records (`ord`; replay[0]
+// counts such rays).  The wave then runs the ordered step next to the order-free one for as long as one of its lanes needs it — a few
+// hundred of a wave's many thousand iterations, for a handful of rays in a million.  (A second launch over a list of the flagged rays
+// cost 0.75 - 1.2 ms of a 21 ms launch: a hundred rays, each a chain of some 150 dependent fetches, with the chip otherwise idle.)
 // OCT (with FREE): the order-free walk over the eight-wide records with quantised boxes (rt_oct.h) instead of the quad records.
 template <bool ANY, bool COUNT, bool QUAD, bool FREE = false, bool OCT = false>
 __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene sc, size_t n, const float *__restrict__ rays, int aos, int *out_prim, float *out_t,
                                                            float *out_b1, float *out_b2, uint8_t *out_any, int *spill, unsigned long long *work, int leaf_min,
-                                                           uint32_t *replay = nullptr, const uint32_t *items = nullptr, const uint32_t *n_items = nullptr) {
+                                                           uint32_t *replay = nullptr) {
     static_assert(!FREE || (!ANY && !COUNT && QUAD), "the order-free walk is a closest-hit walk over quad records");
     static_assert(!OCT || FREE, "the eight-wide records serve the order-free walk only");
     constexpr int RING = OCT ? RT_OCT_STACK : (QUAD ? RT_QUAD_STACK : RT_PAIR_STACK);
@@ -234,21 +239,29 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene
     __shared__ float s_st[RING * RT_BLOCK];
     size_t nthreads = (size_t)gridDim.x * blockDim.x, gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     PairStackT<RING> st; st.lds_i = &s_si[threadIdx.x]; st.lds_t = &s_st[threadIdx.x];
-    st.cap = OCT ? sc.oct_stack_cap : (QUAD ? sc.quad_stack_cap : RT_MAX_STACK);
+    st.cap = OCT ? max(sc.oct_stack_cap, sc.quad_stack_cap) : (QUAD ? sc.quad_stack_cap : RT_MAX_STACK);      // (OCT: the second, ordered walk is over the quad records)
     st.spill_i = spill + gtid; st.spill_t = (float *)(spill + (size_t)st.cap * nthreads) + gtid; st.spill_stride = nthreads; st.reset();
     size_t nwaves = nthreads / RT_WAVE, gw = gtid / RT_WAVE;
-    const size_t m = n_items ? (size_t)*n_items : n;      // work items: all n rays, or the listed ones
-    size_t per = ((m + nwaves - 1) / nwaves + RT_WAVE - 1) & ~(size_t)(RT_WAVE - 1);
-    size_t w_lo = gw * per < m ? gw * per : m, w_hi = w_lo + per < m ? w_lo + per : m;
+    size_t per = ((n + nwaves - 1) / nwaves + RT_WAVE - 1) & ~(size_t)(RT_WAVE - 1);
+    size_t w_lo = gw * per < n ? gw * per : n, w_hi = w_lo + per < n ? w_lo + per : n;
     size_t next = w_lo;
+    // FREE: no fixed share; the waves draw runs of RT_TRACE_RUN rays from a counter (replay[2..3], zeroed by the host) until the batch is
+    // used up, so that a wave held up at the end of its work — by a ray on its second, ordered walk, a chain of dependent fetches — holds up
+    // nothing but itself.  One atomic per run and wave; the answers do not depend on which lane walks which ray.
+    bool dry = false;
+    if (FREE) { next = 0; w_hi = 0; }
     long long ri = -1;
     LaneTrav L = {};
     L.mode = RT_LANE_DONE; L.hitSlot = -1;
-    uint32_t nNodes = 0, nTests = 0;
+    uint32_t nNodes = 0, nTests = 0, nReplayed = 0;
     const bool exact_slabs = (leaf_min >> 8) & 1;    // knob: every wave takes the general slab path
     leaf_min &= 255;
+    bool ord = false;                                // FREE: this lane's ray is on its second walk, in the reference's order
     while (true) {
-        if (ri >= 0 && L.mode == RT_LANE_DONE) {   // retire
+        bool again = false;
+        if (FREE && ri >= 0 && L.mode == RT_LANE_DONE && L.amb && !ord) { ord = true; again = true; nReplayed++; }
+        else if (ri >= 0 && L.mode == RT_LANE_DONE) {   // retire
+            ord = false;
             size_t i = (size_t)ri;
             if (ANY) out_any[i] = L.found ? 1 : 0;
             else {
@@ -266,7 +279,6 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene
                         b2 = acosf(clampf(ph.z / sp[0], -1.f, 1.f)) / RT_PI;
                     }
                 }
-                if (FREE && L.amb) { prim = -2; replay[1 + atomicAdd(&replay[0], 1u)] = (uint32_t)i; }
                 out_prim[i] = prim; out_t[i] = L.tmax;
                 if (out_b1) { out_b1[i] = b1; out_b2[i] = b2; }
             }
@@ -276,10 +288,17 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene
         bool fresh = false;
         F3 po = f3(0, 0, 0), pd = f3(0, 0, 1); float ptmax = 0.f;
         uint64_t im = __ballot(ri < 0);
+        if (FREE && im != 0 && next >= w_hi && !dry) {
+            unsigned long long base = 0;
+            if (lane_id() == 0) base = atomicAdd((unsigned long long *)replay + 1, (unsigned long long)RT_TRACE_RUN);
+            base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            dry = base >= n;
+            next = dry ? n : (size_t)base; w_hi = next + RT_TRACE_RUN < n ? next + RT_TRACE_RUN : n;
+        }
         if (im != 0 && next < w_hi) {
             size_t cand = next + prefix_in_mask(im);
             if (ri < 0 && cand < w_hi) {
-                size_t i = items ? (size_t)items[cand] : cand;
+                size_t i = cand;
                 ri = (long long)i;
                 if (aos) { po = f3(rays[7 * i], rays[7 * i + 1], rays[7 * i + 2]); pd = f3(rays[7 * i + 3], rays[7 * i + 4], rays[7 * i + 5]); ptmax = rays[7 * i + 6]; }
                 else { po = f3(rays[i], rays[n + i], rays[2 * n + i]); pd = f3(rays[3 * n + i], rays[4 * n + i], rays[5 * n + i]); ptmax = rays[6 * n + i]; }
@@ -299,14 +318,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene
         if (leafrun) { const float4 *sl = sc.slots + 3 * (size_t)L.cur; pre[0] = sl[0]; pre[1] = sl[1]; pre[2] = sl[2]; }
 #endif
         float entry = 0.f;
-        if (OCT) { if (walk) oct_step_free(sc.octs, L, (uint32_t)L.cur, false, st, info, have, entry); }
-        else if (FREE) { if (walk) lane_walk_quad_free(sc.quads, L, st, info, have, entry); }
-        else if (QUAD) {
+        if (FREE) {
+            if (walk && !ord) { if (OCT) oct_step_free(sc.octs, L, (uint32_t)L.cur, false, st, info, have, entry); else lane_walk_quad_free(sc.quads, L, st, info, have, entry); }
+            if (__ballot(walk && ord) != 0) { if (walk && ord) lane_walk_quad<false>(sc.quads, L, st, info, have); }
+        } else if (QUAD) {
             if (__ballot(walk && !L.plain) == 0 && !exact_slabs) { if (walk) lane_walk_quad<true>(sc.quads, L, st, info, have); }     // the whole wave takes one version
             else if (walk) lane_walk_quad<false>(sc.quads, L, st, info, have);
         } else if (walk) lane_walk<COUNT, false>(sc.pairs, L, st, nNodes, info, have);
         if (FREE) {
-            if (leafrun) {
+            if (leafrun && !ord) {
 #if RT_LEAF_LOAD_AHEAD
                 LeafOutFree r = OCT ? oct_leaf_free(sc, sc.slots, L, st, pre) : lane_leaf_free(sc, sc.slots, L, st, pre);
 #else
@@ -314,6 +334,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene
 #endif
                 L.found = r.found; L.amb = r.amb; L.tmax = r.tmax; L.hitSlot = r.hitSlot; L.b0 = r.b0; L.b1 = r.b1; L.b2 = r.b2;
                 info = r.info; have = r.have; entry = r.entry;
+            }
+            if (__ballot(leafrun && ord) != 0) {
+                if (leafrun && ord) {
+                    LeafOut r = lane_leaf<false, false>(sc, sc.slots, L, st, nTests);
+                    L.found = r.found; L.tmax = r.tmax; L.hitSlot = r.hitSlot; L.b0 = r.b0; L.b1 = r.b1; L.b2 = r.b2;
+                    info = r.info; have = r.have;
+                }
             }
         } else if (leafrun) {
 #if RT_LEAF_LOAD_AHEAD
@@ -329,12 +356,18 @@ __global__ __launch_bounds__(RT_BLOCK, RT_TRACE_OCC) void k_trace_pairs(DevScene
             info = OCT ? 0u : sc.root_info;      // (the root's record is the first of either kind)
             if (OCT && have && !oct_ray_ok(L)) { L.amb = true; have = false; }      // a reciprocal direction too small or too large for the record-space slab test
         }
-        if (walk || leafrun || fresh) { lane_enter(sc, L, info, have); if (FREE) L.entry = entry; }
+        if (FREE && again) {      // the same ray from its start, as BVHAccel::Intersect walks it (the ray's own tMax is in L.t0)
+            uint32_t dummy = 0;
+            have = lane_begin<false>(sc, L, st, L.o, L.d, L.t0, dummy);
+            info = sc.root_info;
+        }
+        if (walk || leafrun || fresh || again) { lane_enter(sc, L, info, have); if (FREE) L.entry = entry; }
     }
     if (COUNT) {
         atomicAdd(&work[0], (unsigned long long)nNodes);
         atomicAdd(&work[1], (unsigned long long)nTests);
     }
+    if (FREE && nReplayed) atomicAdd(&replay[0], nReplayed);      // statistics only
 }
 
 // ------------------------------------------------------------------ raygen --
@@ -2155,7 +2188,7 @@ struct rt_scene {
     DevBuf d_nodes, d_slots, d_frames, d_uv, d_spheres, d_slot_mat, d_slot_light, d_mats, d_tex, d_lights, d_envs, d_light_cdf, d_spill, d_pairs, d_quads, d_flat, d_octs;
     int interior_depth = 0;
     std::vector<DevBuf *> d_texels;
-    DevBuf d_trace_io, d_work, d_replay;      // d_replay: count + indices of the rays the order-free batch trace hands to the ordered one
+    DevBuf d_trace_io, d_work, d_replay;      // d_replay: number of rays the order-free batch trace walked a second time, in the reference's order
     size_t spill_bytes = 0;
     // Rendering runs as up to RT_MAX_LANES independent wavefront pipelines ("lanes") at once, each on its own HIP stream with its own
     // queues, over its own share of the samples (rt_render_device).  Lane 0 runs on the context's stream and owns the result buffer.
@@ -2702,16 +2735,14 @@ static void launch_trace(rt_scene *this_, int grid, size_t n, const float *rays,
         hipLaunchKernelGGL((k_trace_batch<ANY, COUNT>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
                            spill, work);
     else if (!ANY && !COUNT && this_->dev.quads && replay) {
-        // closest hits without the reference's visit order, then the rays whose answer that order could change, in that order
-        (void)hipMemsetAsync(replay, 0, 4, ctx->stream);
+        // closest hits without the reference's visit order; the rays whose answer that order could change are walked again in it inside the launch
+        (void)hipMemsetAsync(replay, 0, 16, ctx->stream);      // [0] rays walked a second time, [2..3] the waves' ray counter
         if (this_->dev.octs && env_int("RT_AMD_OCT_WALK", 1))
             hipLaunchKernelGGL((k_trace_pairs<false, false, true, true, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
-                               spill, work, tune_leaf_min(), replay, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                               spill, work, tune_leaf_min(), replay);
         else
         hipLaunchKernelGGL((k_trace_pairs<false, false, true, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
-                           spill, work, tune_leaf_min(), replay, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
-        hipLaunchKernelGGL((k_trace_pairs<false, false, true>), dim3(std::min(grid, 64)), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
-                           spill, work, tune_leaf_min(), (uint32_t *)nullptr, (const uint32_t *)(replay + 1), (const uint32_t *)replay);
+                           spill, work, tune_leaf_min(), replay);
     } else if (!COUNT && this_->dev.quads)
         hipLaunchKernelGGL((k_trace_pairs<ANY, false, true>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, this_->dev, n, rays, aos, prim, t, b1, b2, any_out,
                            spill, work, tune_leaf_min());
@@ -2735,7 +2766,7 @@ static int trace_host(rt_scene *this_, bool any, size_t n, const float *o, const
     char *outp = base + ((in_bytes + 255) & ~(size_t)255);
     int grid = (int)std::min<size_t>((n + RT_BLOCK - 1) / RT_BLOCK, (size_t)ctx->n_cu * trace_blocks_per_cu());
     uint32_t *replay = nullptr;
-    if (!any && free_walk_enabled(this_)) { HIP_OK(this_->d_replay.ensure(4 * (n + 1))); replay = (uint32_t *)this_->d_replay.p; }
+    if (!any && free_walk_enabled(this_)) { HIP_OK(this_->d_replay.ensure(16)); replay = (uint32_t *)this_->d_replay.p; }
     if (any)
         launch_trace<true, false>(this_, grid, n, (const float *)base, 1, nullptr, nullptr, nullptr, nullptr, (uint8_t *)outp, nullptr);
     else
@@ -2782,7 +2813,7 @@ int rt_trace_closest_device(rt_scene *this_, size_t n, const void *rays, void *h
         if (stats) { stats->nodes_visited = w[0]; stats->prims_tested = w[1]; }
     }
     uint32_t *replay = nullptr;
-    if (free_walk_enabled(this_)) { HIP_OK(this_->d_replay.ensure(4 * (n + 1))); replay = (uint32_t *)this_->d_replay.p; }
+    if (free_walk_enabled(this_)) { HIP_OK(this_->d_replay.ensure(16)); replay = (uint32_t *)this_->d_replay.p; }
     EventPair ev;
     HIP_OK(ev.create());
     HIP_OK(hipEventRecord(ev.a, ctx->stream));
