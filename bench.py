@@ -117,10 +117,10 @@ def traversal_roofline(ctx, n_tris, n_rays, repeats, bounces=4, ray_slice=None):
                     stale = os.path.relpath(f, ROOT)
     except Exception:
         traffic = None
-    # The timed launch is the order-free walk over eight-wide records (three tree levels per 128-byte line) plus the ordered replay of the few
+    # The timed launch is the order-free walk over eight-wide records (three tree levels per 128-byte line) including the second, ordered walk of the few
     # near-ties; the ALGORITHMIC bytes are those of the reference's own walk (32 B per node it slab-tests, counted by the ordered counting
     # kernel), so achieved = algorithmic bytes / time can exceed what the memory system moves: `traffic` (PMC) is the real figure.
-    out = {"bound": "hbm", "kernel": traffic_kernel or "k_trace_pairs (closest hit; order-free over eight-wide quantised records where the scene has them, + ordered replay)",
+    out = {"bound": "hbm", "kernel": traffic_kernel or "k_trace_pairs (closest hit; order-free over eight-wide quantised records where the scene has them, near-ties walked again in the reference's order inside the launch)",
            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch (PMC, %s)" % traffic_src if traffic else None,
            "traffic_note": None if traffic else (("%s was measured on another build of librt_amd.so" % stale) if stale else "no PMC summary for this workload"),

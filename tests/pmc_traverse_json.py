@@ -11,14 +11,14 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         if not k.startswith("k_trace_pairs<false, false"):      # closest hit, not the counting variant
             continue
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); launches[k][r["Counter_Name"]].add(r["Dispatch_Id"])
-# the timed launch is the kernel that moves the most data; the ordered variant also appears as the (tiny) replay launch of the order-free one,
-# so per-launch means are taken per kernel and the replay's are added to the main launch's
+# the timed launch is the kernel that moves the most data (the order-free kernel walks its near-ties again in the reference's order itself;
+# should an ordered launch of the same batch appear next to it, as earlier builds had for those rays, its means are added)
 def per_launch(k):
     return {n: v / max(1, len(launches[k][n])) for n, v in acc[k].items()}
 main = max(acc, key=lambda k: acc[k].get("TCC_EA0_RDREQ_sum", acc[k].get("TCC_EA0_RDREQ", 0.0)) / max(1, len(launches[k].get("TCC_EA0_RDREQ_sum", launches[k].get("TCC_EA0_RDREQ", [1])))))
 per = per_launch(main)
-names = {"k_trace_pairs<false, false, true, true, true>": "closest hit, order-free over eight-wide quantised records (+ ordered replay of near-ties)",
-         "k_trace_pairs<false, false, true, true, false>": "closest hit, order-free over quad records (+ ordered replay of near-ties)",
+names = {"k_trace_pairs<false, false, true, true, true>": "closest hit, order-free over eight-wide quantised records (near-ties walked again in the reference's order inside the launch)",
+         "k_trace_pairs<false, false, true, true, false>": "closest hit, order-free over quad records (near-ties walked again in the reference's order inside the launch)",
          "k_trace_pairs<false, false, true, false, false>": "closest hit, quad records, reference order"}
 replay = [k for k in acc if k != main and "true, true" in main and k == "k_trace_pairs<false, false, true, false, false>"]
 for k in replay:
@@ -39,4 +39,4 @@ print(json.dumps({"kernel": "%s (%s)" % (main, names.get(main, "")), "workload":
                   "traffic_bytes_per_launch": reads + writes,
                   "method": "reads = sum over request sizes of TCC_EA0_RDREQ_<size> x size (requests of unlisted size counted at 64 B); writes = WRITE_SIZE; "
                             "separate rocprofv3 --pmc passes over tests/prof_traverse.py (tests/pmc_traverse.sh), mean over the launches of the timed kernel"
-                            " (plus its replay launch)"}, indent=1))
+                            " (the ordered second walk of near-ties runs inside it)"}, indent=1))
