@@ -286,9 +286,10 @@ int rt_trace_closest_device(rt_scene *scene, size_t n, const void *rays, void *h
  * into a graph as it stands.)  It has no counterpart in the reference.  The call allocates nothing: the traversal stacks' spill area
  * and the work counters, which the other entry points keep in buffers the library allocates, live in a static array of 32 MiB +
  * 256 bytes in device memory that every GPU the library runs on holds until the process ends (its address is taken once per
- * context, in rt_init).  The kernels and their results are those of rt_trace_closest_device; only the grid is cut down to the
+ * context, in rt_init).  The results are those of rt_trace_closest_device, bit for bit (the walk is always the one in the reference's
+ * order over the quad records, which needs nothing beyond the stacks); the grid is cut down to the
  * blocks whose lanes' stacks fit the array: 32 MiB / (256 lanes x 8 bytes x max(64, 3 * (interior levels / 2 + 1) + 2) entries),
- * i.e. 256 blocks for trees of up to 40 interior levels and 162 at the 64 levels rt_scene_create accepts.  The two HIP events that
+ * i.e. 256 blocks for trees of up to 39 interior levels and 162 at the 64 levels rt_scene_create accepts.  The two HIP events that
  * time the launch belong to the context and are shared by its scenes.  Limits, refused with an error: n > 2^28 rays; count_work
  * without stats.  All calls on one GPU share that GPU's array, so calls that overlap on one GPU (two contexts on the same device,
  * from two threads) race; the array keeps the last call's contents, and the call clears the part that must start at zero (the
