@@ -143,10 +143,14 @@ def test_traversal_variants_agree(host_scene, gpu_ctx, monkeypatch):
     ds = ra.DeviceScene(gpu_ctx, hs.desc_ptr)
     base = ds.trace_closest(o, d, tmax); base_any = ds.trace_any(o, d, tmax)
     # the batch trace without the reference's visit order (nearest first, near-ties and non-plain rays replayed in that order)
-    monkeypatch.setenv("RT_AMD_FREE_WALK", "1")
-    free = ds.trace_closest(o, d, tmax)
-    monkeypatch.delenv("RT_AMD_FREE_WALK")
-    assert np.array_equal(base[0], free[0]) and np.array_equal(base[1].view(np.uint32), free[1].view(np.uint32)) and np.array_equal(base[2].view(np.uint32), free[2].view(np.uint32))
+    # ... over the eight-wide records (the default for this tree), over the quad records, and the walk in the reference's order alone
+    for env in ({"RT_AMD_FREE_WALK": "1"}, {"RT_AMD_FREE_WALK": "1", "RT_AMD_OCT_WALK": "0"}, {"RT_AMD_FREE_WALK": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        free = ds.trace_closest(o, d, tmax)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(base[0], free[0]) and np.array_equal(base[1].view(np.uint32), free[1].view(np.uint32)) and np.array_equal(base[2].view(np.uint32), free[2].view(np.uint32)), env
     monkeypatch.setenv("RT_AMD_EXACT_SLABS", "1")
     alt = ds.trace_closest(o, d, tmax); alt_any = ds.trace_any(o, d, tmax)
     monkeypatch.delenv("RT_AMD_EXACT_SLABS")
